@@ -1,0 +1,144 @@
+/*
+ * tdk_hip.h -- C ABI of libtdk_hip.so, the MI355X (gfx950) RAW-ISP kernel library.
+ *
+ * This is the drop-in boundary for the hot path of uc-vision/torch-darktable.  Each entry
+ * point replaces one op (or workspace method) that the reference registers on its pybind11
+ * module `torch_darktable.torch_darktable_extension` (reference csrc/extension.cpp:50-248,
+ * typed by torch_darktable_extension.pyi); the reference file:line each one stands in for
+ * is cited on the declaration.  A binding (ctypes / cgo / JNI / pybind) allocates outputs,
+ * selects the device, and passes raw device pointers + sizes + the HIP stream.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current HIP device unless named host_*;
+ *  - images are row-major HWC (channels innermost), `width`/`height` in pixels;
+ *  - `dtype` selects the STORAGE type of image operands: TDK_F32 (the reference's only
+ *    mode) or TDK_F16 (extension: fp16 storage, fp32 arithmetic);
+ *  - `pattern` is the reference's BayerPattern word (csrc/debayer/demosaic.h:7-12);
+ *  - `stream` is a hipStream_t (NULL = the legacy default stream); all work is enqueued
+ *    asynchronously, nothing synchronises the host, nothing allocates device memory;
+ *  - scratch comes from the caller: tdk_*_workspace_bytes() reports the size, the caller
+ *    passes a device buffer of at least that many bytes, 256-byte aligned;
+ *  - return value: TDK_OK (0) or a tdk_status code; tdk_last_error() gives the message
+ *    of the last failure on the calling thread.
+ */
+#ifndef TDK_HIP_H
+#define TDK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDK_ABI_VERSION 1
+
+typedef void* tdk_stream_t; /* hipStream_t */
+
+enum tdk_status { TDK_OK = 0, TDK_ERR_INVALID_ARGUMENT = 1, TDK_ERR_LAUNCH = 2, TDK_ERR_UNSUPPORTED = 3 };
+enum tdk_dtype { TDK_F32 = 0, TDK_F16 = 1 };
+
+#define TDK_PATTERN_RGGB 0x94949494u
+#define TDK_PATTERN_BGGR 0x16161616u
+#define TDK_PATTERN_GRBG 0x61616161u
+#define TDK_PATTERN_GBRG 0x49494949u
+
+int tdk_abi_version(void);
+const char* tdk_last_error(void);
+
+/* ---- 12-bit packed raw codec: reference csrc/packed.cu:158-280 (extension.cpp:159-169).
+ * Flat buffers, `num_pairs` pixel pairs <-> 3 * num_pairs bytes. */
+int tdk_encode12_u16(const uint16_t* in, uint8_t* out, int64_t num_pairs, int ids_format, tdk_stream_t stream);
+int tdk_encode12_f32(const float* in, uint8_t* out, int64_t num_pairs, int ids_format, int scaled, tdk_stream_t stream);
+int tdk_decode12_f32(const uint8_t* in, float* out, int64_t num_pairs, int ids_format, int scaled, tdk_stream_t stream);
+int tdk_decode12_f16(const uint8_t* in, void* out_half, int64_t num_pairs, int ids_format, int scaled, tdk_stream_t stream);
+int tdk_decode12_u16(const uint8_t* in, uint16_t* out, int64_t num_pairs, int ids_format, tdk_stream_t stream);
+
+/* ---- demosaic.  bayer: (H, W) ; rgb: (H, W, 3) */
+/* bilinear5x5_demosaic: reference csrc/debayer/bilinear.cu:104-148 (extension.cpp:205-206) */
+int tdk_bilinear5x5(const void* bayer, void* rgb, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream);
+
+/* PPG.process: reference csrc/debayer/ppg.cu:413-464 (extension.cpp:57-65).
+ * median_threshold > 0 enables the pre-median and needs width*height*4 bytes of scratch. */
+size_t tdk_ppg_workspace_bytes(int width, int height, float median_threshold);
+int tdk_ppg(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, float median_threshold,
+            int dtype, tdk_stream_t stream);
+
+/* RCD.process: reference csrc/debayer/rcd.cu:601-671 (extension.cpp:67-74).  Pure function
+ * with the reference's first-call (zero-initialised scratch) semantics.  width must be even. */
+size_t tdk_rcd_workspace_bytes(int width, int height);
+int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream);
+
+/* PostProcess.process: reference csrc/debayer/postprocess.cu:311-390 (extension.cpp:77-90).
+ * in and out must not alias.  The global green ratio is computed and consumed on the
+ * device (no host sync). */
+size_t tdk_postprocess_workspace_bytes(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global);
+int tdk_postprocess(const float* rgb_in, float* rgb_out, void* workspace, int width, int height, uint32_t pattern,
+                    int color_smoothing_passes, int green_eq_local, int green_eq_global, float green_eq_threshold,
+                    tdk_stream_t stream);
+
+/* apply_white_balance: reference csrc/white_balance.cu:164-183 (extension.cpp:209-210).
+ * gains: 3 floats on the DEVICE (no host read-back). out may alias in. */
+int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float* gains, int width, int height, uint32_t pattern,
+                            tdk_stream_t stream);
+
+/* ---- colour operators: reference csrc/color_conversions.cu (extension.cpp:127-156).
+ * (H, W, 3) -> (H, W, 3), npix = H * W. */
+enum tdk_color_op {
+  TDK_RGB_TO_XYZ = 0, TDK_XYZ_TO_LAB = 1, TDK_LAB_TO_XYZ = 2, TDK_XYZ_TO_RGB = 3, TDK_RGB_TO_LAB = 4, TDK_LAB_TO_RGB = 5,
+  TDK_MODIFY_HSL = 6,      /* params = {hue_adjust, sat_adjust, lum_adjust}   color_conversions.cu:143-145 */
+  TDK_MODIFY_VIBRANCE = 7, /* params = {amount}                               color_conversions.cu:147-149 */
+  TDK_TRANSFORM_3X3 = 8    /* device_matrix = 9 row-major floats ON DEVICE    color_conversions.cu:153-161 */
+};
+int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
+                 tdk_stream_t stream);
+
+/* compute_luminance / compute_log_luminance: color_conversions.cu:226-233.  rgb (H,W,3) -> lum (H,W) */
+int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, int log_mode, float eps, int rgb_dtype, int lum_dtype,
+                          tdk_stream_t stream);
+/* modify_luminance / modify_log_luminance: color_conversions.cu:307-314 */
+int tdk_modify_luminance(const void* rgb, const void* lum, void* rgb_out, int64_t npix, int log_mode, int rgb_dtype, int lum_dtype,
+                         tdk_stream_t stream);
+
+/* ---- image statistics + tonemaps: reference csrc/tonemap/ (extension.cpp:172-195) */
+/* compute_image_bounds: color_adaption.cu:90-120.  bounds[2] on device; call tdk_image_bounds_init
+ * once, then tdk_image_bounds_accumulate per image. */
+int tdk_image_bounds_init(float* bounds, tdk_stream_t stream);
+int tdk_image_bounds_accumulate(const void* rgb, int width, int height, int stride, float* bounds, int dtype, tdk_stream_t stream);
+/* compute_image_metrics: color_adaption.cu:122-166.  acc: 8 floats of device scratch, zeroed by
+ * _init; bounds: 2 device floats ({0,1} unless rescaling); _finish writes metrics[5] on device
+ * (normalised by max(valid, 1)) without a host sync. */
+int tdk_image_metrics_init(float* acc, tdk_stream_t stream);
+int tdk_image_metrics_accumulate(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc,
+                                 int dtype, tdk_stream_t stream);
+int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream);
+
+enum tdk_tonemap { TDK_TONEMAP_REINHARD = 0, TDK_TONEMAP_ACES = 1, TDK_TONEMAP_ACES_ADAPTIVE = 2, TDK_TONEMAP_LINEAR = 3 };
+/* reinhard_tonemap / aces_tonemap / adaptive_aces_tonemap / linear_tonemap:
+ * reinhard.cu:48-81, aces.cu:92-154, linear.cu:43-76.  rgb (H,W,3) -> u8 (H,W,3).
+ * metrics: 5 device floats (ignored by TDK_TONEMAP_ACES, may be NULL there). */
+int tdk_tonemap(const void* rgb, uint8_t* out, int64_t npix, int mode, const float* metrics, float gamma, float intensity,
+                float light_adapt, float vibrance, int dtype, tdk_stream_t stream);
+
+/* ---- Wiener.process: reference csrc/denoise/denoise.cu:266-345 (extension.cpp:215-223).
+ * image (H, W, C), C in {1,3}; sigmas: C device floats; tile_size in {16,32}; overlap in {2,4,8}. */
+size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor);
+int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
+               const float* sigmas, int dtype, tdk_stream_t stream);
+
+/* ---- Bilateral.process: reference csrc/local_contrast/bilateral.cu:358-385 (extension.cpp:111-121) */
+int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]);
+size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
+int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
+                  float detail, int dtype, tdk_stream_t stream);
+
+/* ---- Laplacian.process: reference csrc/local_contrast/laplacian.cu:433-480 (extension.cpp:94-108).
+ * num_gamma must be 6 (laplacian.cu:625-634). */
+size_t tdk_laplacian_workspace_bytes(int width, int height, int num_gamma);
+int tdk_laplacian(const float* lum_in, float* lum_out, void* workspace, int width, int height, int num_gamma, float sigma,
+                  float shadows, float highlights, float clarity, tdk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

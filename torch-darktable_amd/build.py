@@ -1,0 +1,74 @@
+"""Builds libtdk_hip.so (gfx950) in-tree with hipcc: one object per .hip file, in parallel.
+
+  python torch-darktable_amd/build.py [--force] [--jobs N]
+
+The library lands next to the Python package (torch_darktable/libtdk_hip.so) so it travels
+with the source tree; no JIT cache, no torch headers.
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / 'csrc'
+OBJ = HERE / 'build'
+LIB = HERE / 'torch_darktable' / 'libtdk_hip.so'
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+# -ffp-contract=off: no FMA contraction, so + - * / kernels match the strict-fp32 oracle bit for bit.
+CXXFLAGS = ['-O3', '-std=c++17', f'--offload-arch={ARCH}', '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',
+            '-Wall', '-Wno-unused-function']
+
+
+def _stale(target: Path, deps) -> bool:
+  return (not target.exists()) or any(d.stat().st_mtime > target.stat().st_mtime for d in deps)
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> Path:
+  OBJ.mkdir(exist_ok=True)
+  headers = list(CSRC.glob('*.h')) + [HERE.parent / 'include' / 'tdk_hip.h']
+  sources = sorted(CSRC.glob('*.hip'))
+  todo = []
+  objs = []
+  for src in sources:
+    obj = OBJ / (src.stem + '.o')
+    objs.append(obj)
+    if force or _stale(obj, [src, *headers]):
+      todo.append((src, obj))
+
+  def compile_one(job):
+    src, obj = job
+    cmd = [HIPCC, *CXXFLAGS, '-c', str(src), '-o', str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'hipcc failed for {src.name}:\n{r.stderr}')
+    if verbose and r.stderr.strip():
+      print(r.stderr, file=sys.stderr)
+    return src.name
+
+  if todo:
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+      for name in ex.map(compile_one, todo):
+        if verbose:
+          print(f'  compiled {name}')
+  if todo or force or _stale(LIB, objs):
+    cmd = [HIPCC, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB), *map(str, objs)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'link failed:\n{r.stderr}')
+  return LIB
+
+
+if __name__ == '__main__':
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--force', action='store_true')
+  ap.add_argument('--jobs', type=int, default=None)
+  args = ap.parse_args()
+  print(build(force=args.force, jobs=args.jobs, verbose=True))

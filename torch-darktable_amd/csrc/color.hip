@@ -1,0 +1,220 @@
+// color.hip -- per-pixel colour operators and luminance extract / replace.
+//
+// Replaces reference csrc/color_conversions.cu:78-314 (convert_color_kernel with its nine
+// functors, extract_channel_kernel, modify_color_kernel).  Math: tdk_color.h namespace cA
+// (the reference's device_conversions.h).
+//
+// MI355X design: streaming kernels over the flattened pixel list; each thread owns four
+// consecutive pixels, i.e. 48 contiguous bytes in and out (three 16-B accesses, 3 KiB per
+// wave), grid-strided over at most 8 workgroups per CU.  The reference's 16x16 2-D blocks
+// with three scalar 4-B loads per pixel are gone.  Unaligned buffers or a pixel count that
+// is not a multiple of four fall back to the one-pixel-per-thread tail kernel.
+// color_transform_3x3 reads its matrix on the device (the reference dereferences the device
+// pointer on the host, color_conversions.cu:158-159).
+#include "tdk_color.h"
+
+namespace {
+
+struct OpArgs {
+  float p0, p1, p2;
+  const float* matrix;
+};
+
+template <int OP> __device__ __forceinline__ f3 apply_op(f3 c, const OpArgs& a, const float m[9]) {
+  if constexpr (OP == TDK_RGB_TO_XYZ) return cA::rgb_to_xyz(c);
+  else if constexpr (OP == TDK_XYZ_TO_LAB) return cA::xyz_to_lab(c);
+  else if constexpr (OP == TDK_LAB_TO_XYZ) return cA::lab_to_xyz(c);
+  else if constexpr (OP == TDK_XYZ_TO_RGB) return cA::xyz_to_rgb(c);
+  else if constexpr (OP == TDK_RGB_TO_LAB) return cA::rgb_to_lab(c);
+  else if constexpr (OP == TDK_LAB_TO_RGB) return cA::lab_to_rgb(c);
+  else if constexpr (OP == TDK_MODIFY_HSL) return cA::modify_hsl(c, a.p0, a.p1, a.p2);
+  else if constexpr (OP == TDK_MODIFY_VIBRANCE) return cA::vibrance(c, a.p0);
+  else return clip3(mat3_mul(m, c));  // device_conversions.h:209-211
+}
+
+inline int stream_grid(int64_t nthreads) {
+  int64_t b = tdk_div_up64(nthreads, 256);
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+template <int OP> __global__ __launch_bounds__(256) void color_vec4(const float* __restrict__ in, float* __restrict__ out, int64_t ngroups, OpArgs a) {
+  float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (OP == TDK_TRANSFORM_3X3) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = a.matrix[k];
+  }
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    float v[12];
+    rgb4_io<float>::load(in, g, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f3 r = apply_op<OP>(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), a, m);
+      v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+    }
+    rgb4_io<float>::store(out, g, v);
+  }
+}
+
+template <int OP> __global__ __launch_bounds__(256) void color_tail(const float* __restrict__ in, float* __restrict__ out, int64_t first, int64_t npix, OpArgs a) {
+  float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (OP == TDK_TRANSFORM_3X3) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = a.matrix[k];
+  }
+  for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const f3 r = apply_op<OP>(mk3(in[3 * i], in[3 * i + 1], in[3 * i + 2]), a, m);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+  }
+}
+
+template <int OP> int run_color(const float* in, float* out, int64_t npix, OpArgs a, hipStream_t s) {
+  int64_t done = 0;
+  if (tdk_aligned(in, 16) && tdk_aligned(out, 16) && npix >= 4) {
+    const int64_t ng = npix / 4;
+    hipLaunchKernelGGL(color_vec4<OP>, dim3(stream_grid(ng)), dim3(256), 0, s, in, out, ng, a);
+    TDK_CHECK_LAUNCH("tdk_color_op");
+    done = ng * 4;
+  }
+  if (done < npix) {
+    hipLaunchKernelGGL(color_tail<OP>, dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, a);
+    TDK_CHECK_LAUNCH("tdk_color_op");
+  }
+  return TDK_OK;
+}
+
+// ---- luminance extract: rgb (T_RGB) -> plane (T_L)
+template <typename TR, typename TL, bool LOG>
+__global__ __launch_bounds__(256) void lum_extract_vec4(const TR* __restrict__ rgb, TL* __restrict__ lum, int64_t ngroups, float eps) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    float v[12], l[4];
+    rgb4_io<TR>::load(rgb, g, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float y = cA::rgb_to_lab_l(clip3(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2])));
+      l[k] = LOG ? logf(fmaxf(eps, y)) : y;
+    }
+    s4_io<TL>::store(lum, g, l);
+  }
+}
+template <typename TR, typename TL, bool LOG>
+__global__ __launch_bounds__(256) void lum_extract_tail(const TR* __restrict__ rgb, TL* __restrict__ lum, int64_t first, int64_t npix, float eps) {
+  for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const float y = cA::rgb_to_lab_l(clip3(mk3(ld(rgb, 3 * i), ld(rgb, 3 * i + 1), ld(rgb, 3 * i + 2))));
+    st(lum, i, LOG ? logf(fmaxf(eps, y)) : y);
+  }
+}
+
+// ---- luminance replace
+template <typename TR, typename TL, bool LOG>
+__global__ __launch_bounds__(256) void lum_modify_vec4(const TR* __restrict__ rgb, const TL* __restrict__ lum, TR* __restrict__ out, int64_t ngroups) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    float v[12], l[4];
+    rgb4_io<TR>::load(rgb, g, v);
+    s4_io<TL>::load(lum, g, l);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f3 c = mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+      const f3 r = LOG ? cA::modify_log_luminance(c, l[k]) : cA::modify_luminance(c, l[k]);
+      v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+    }
+    rgb4_io<TR>::store(out, g, v);
+  }
+}
+template <typename TR, typename TL, bool LOG>
+__global__ __launch_bounds__(256) void lum_modify_tail(const TR* __restrict__ rgb, const TL* __restrict__ lum, TR* __restrict__ out, int64_t first, int64_t npix) {
+  for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const f3 c = mk3(ld(rgb, 3 * i), ld(rgb, 3 * i + 1), ld(rgb, 3 * i + 2));
+    const f3 r = LOG ? cA::modify_log_luminance(c, ld(lum, i)) : cA::modify_luminance(c, ld(lum, i));
+    st(out, 3 * i, r.x); st(out, 3 * i + 1, r.y); st(out, 3 * i + 2, r.z);
+  }
+}
+
+template <typename TR, typename TL, bool LOG>
+int run_extract(const void* rgb_, void* lum_, int64_t npix, float eps, hipStream_t s) {
+  const TR* rgb = reinterpret_cast<const TR*>(rgb_);
+  TL* lum = reinterpret_cast<TL*>(lum_);
+  int64_t done = 0;
+  if (tdk_aligned(rgb, 16) && tdk_aligned(lum, 16) && npix >= 4) {
+    const int64_t ng = npix / 4;
+    hipLaunchKernelGGL((lum_extract_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, ng, eps);
+    TDK_CHECK_LAUNCH("tdk_compute_luminance");
+    done = ng * 4;
+  }
+  if (done < npix) {
+    hipLaunchKernelGGL((lum_extract_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, done, npix, eps);
+    TDK_CHECK_LAUNCH("tdk_compute_luminance");
+  }
+  return TDK_OK;
+}
+
+template <typename TR, typename TL, bool LOG>
+int run_modify(const void* rgb_, const void* lum_, void* out_, int64_t npix, hipStream_t s) {
+  const TR* rgb = reinterpret_cast<const TR*>(rgb_);
+  const TL* lum = reinterpret_cast<const TL*>(lum_);
+  TR* out = reinterpret_cast<TR*>(out_);
+  int64_t done = 0;
+  if (tdk_aligned(rgb, 16) && tdk_aligned(lum, 16) && tdk_aligned(out, 16) && npix >= 4) {
+    const int64_t ng = npix / 4;
+    hipLaunchKernelGGL((lum_modify_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, out, ng);
+    TDK_CHECK_LAUNCH("tdk_modify_luminance");
+    done = ng * 4;
+  }
+  if (done < npix) {
+    hipLaunchKernelGGL((lum_modify_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, out, done, npix);
+    TDK_CHECK_LAUNCH("tdk_modify_luminance");
+  }
+  return TDK_OK;
+}
+
+}  // namespace
+
+TDK_EXPORT int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
+                            tdk_stream_t stream) {
+  TDK_REQUIRE(npix >= 0, "tdk_color_op: negative pixel count");
+  if (npix == 0) return TDK_OK;
+  TDK_REQUIRE(in && out, "tdk_color_op: null pointer");
+  OpArgs a{0.0f, 0.0f, 0.0f, device_matrix};
+  if (host_params) { a.p0 = host_params[0]; a.p1 = host_params[1]; a.p2 = host_params[2]; }
+  hipStream_t s = tdk_stream(stream);
+  switch (op) {
+    case TDK_RGB_TO_XYZ: return run_color<TDK_RGB_TO_XYZ>(in, out, npix, a, s);
+    case TDK_XYZ_TO_LAB: return run_color<TDK_XYZ_TO_LAB>(in, out, npix, a, s);
+    case TDK_LAB_TO_XYZ: return run_color<TDK_LAB_TO_XYZ>(in, out, npix, a, s);
+    case TDK_XYZ_TO_RGB: return run_color<TDK_XYZ_TO_RGB>(in, out, npix, a, s);
+    case TDK_RGB_TO_LAB: return run_color<TDK_RGB_TO_LAB>(in, out, npix, a, s);
+    case TDK_LAB_TO_RGB: return run_color<TDK_LAB_TO_RGB>(in, out, npix, a, s);
+    case TDK_MODIFY_HSL: return run_color<TDK_MODIFY_HSL>(in, out, npix, a, s);
+    case TDK_MODIFY_VIBRANCE: return run_color<TDK_MODIFY_VIBRANCE>(in, out, npix, a, s);
+    case TDK_TRANSFORM_3X3:
+      TDK_REQUIRE(device_matrix != nullptr, "tdk_color_op: TDK_TRANSFORM_3X3 needs a device matrix");
+      return run_color<TDK_TRANSFORM_3X3>(in, out, npix, a, s);
+    default: tdk_set_error("tdk_color_op: unknown op %d", op); return TDK_ERR_INVALID_ARGUMENT;
+  }
+}
+
+#define TDK_LUM_DISPATCH(FN, ...)                                                                    \
+  do {                                                                                               \
+    if (rgb_dtype == TDK_F32 && lum_dtype == TDK_F32) return log_mode ? FN<float, float, true>(__VA_ARGS__) : FN<float, float, false>(__VA_ARGS__); \
+    if (rgb_dtype == TDK_F16 && lum_dtype == TDK_F32) return log_mode ? FN<__half, float, true>(__VA_ARGS__) : FN<__half, float, false>(__VA_ARGS__); \
+    if (rgb_dtype == TDK_F16 && lum_dtype == TDK_F16) return log_mode ? FN<__half, __half, true>(__VA_ARGS__) : FN<__half, __half, false>(__VA_ARGS__); \
+    if (rgb_dtype == TDK_F32 && lum_dtype == TDK_F16) return log_mode ? FN<float, __half, true>(__VA_ARGS__) : FN<float, __half, false>(__VA_ARGS__); \
+    tdk_set_error("unsupported dtype combination (%d, %d)", rgb_dtype, lum_dtype);                   \
+    return TDK_ERR_INVALID_ARGUMENT;                                                                 \
+  } while (0)
+
+TDK_EXPORT int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, int log_mode, float eps, int rgb_dtype, int lum_dtype,
+                                     tdk_stream_t stream) {
+  TDK_REQUIRE(npix >= 0, "tdk_compute_luminance: negative pixel count");
+  if (npix == 0) return TDK_OK;
+  TDK_REQUIRE(rgb && lum, "tdk_compute_luminance: null pointer");
+  TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
+  TDK_LUM_DISPATCH(run_extract, rgb, lum, npix, eps, tdk_stream(stream));
+}
+
+TDK_EXPORT int tdk_modify_luminance(const void* rgb, const void* lum, void* rgb_out, int64_t npix, int log_mode, int rgb_dtype,
+                                    int lum_dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(npix >= 0, "tdk_modify_luminance: negative pixel count");
+  if (npix == 0) return TDK_OK;
+  TDK_REQUIRE(rgb && lum && rgb_out, "tdk_modify_luminance: null pointer");
+  TDK_LUM_DISPATCH(run_modify, rgb, lum, rgb_out, npix, tdk_stream(stream));
+}

@@ -1,0 +1,172 @@
+// ppg.hip -- Pattern Pixel Grouping demosaic.
+//
+// Replaces reference csrc/debayer/ppg.cu:21-476 (PPGImpl::process: border_interpolate,
+// pre_median, ppg_demosaic_green, ppg_demosaic_redblue -- 3-4 launches, a zero-filled output
+// and a persistent float3 temp image).
+//
+// MI355X design: ONE fused kernel.  A 256-thread workgroup owns a 64 x 32 output tile:
+//   1. raw CFA tile + 4-px halo -> LDS (zero outside the image), coalesced row reads;
+//   2. the reference's intermediate "green + sparse R/B" image is produced only for the
+//      66 x 34 region the tile needs, straight into three LDS planes (3-px image ring from
+//      the 3x3 same-colour average, everything else from the gradient-selected green);
+//   3. red/blue fill reads that LDS region and each thread emits 4 consecutive pixels as
+//      three 16-B stores.
+// HBM traffic is the compulsory 4 + 12 B/px (fp32) instead of ~52 B/px; the intermediate
+// never leaves the CU.  Arithmetic is add/mul/abs/min/max only, same term order as the oracle,
+// so results are bit-exact.  The optional pre-median stays a separate plane-to-plane kernel
+// (its 5x5 cross footprint would double the halo for a feature the presets leave off).
+#include "tdk_stencils.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 32;
+constexpr int RH = 4;                       // raw halo: 1 (red/blue) + 3 (green)
+constexpr int RW_ = TW + 2 * RH, RHT = TH + 2 * RH;   // 72 x 40
+constexpr int RS = RW_ + 1;                 // padded LDS row stride
+constexpr int GW = TW + 2, GH = TH + 2;     // 66 x 34 intermediate region
+constexpr int GS = GW + 1;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width,
+                                                 int height, uint32_t pattern, int vec_ok) {
+  __shared__ float raw[RHT * RS];
+  __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+
+  for (int i = threadIdx.x; i < RW_ * RHT; i += 256) {
+    const int r = i / RW_, c = i - r * RW_;
+    const int gx = x0 - RH + c, gy = y0 - RH + r;
+    raw[r * RS + c] = (gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld(src, (size_t)gy * width + gx) : 0.0f;
+  }
+  __syncthreads();
+
+  for (int i = threadIdx.x; i < GW * GH; i += 256) {
+    const int r = i / GW, c = i - r * GW;
+    const int gx = x0 - 1 + c, gy = y0 - 1 + r;
+    f3 v = mk3(0.0f, 0.0f, 0.0f);
+    if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
+      if (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3) {
+        v = border_average([&](int xx, int yy) { return ld(orig, (size_t)yy * width + xx); }, gx, gy, width, height, pattern);
+      } else {
+        const float* ctr = raw + (r + RH - 1) * RS + (c + RH - 1);
+        const int cc = cfa_color(gy, gx, pattern);
+        const float pc = ctr[0];
+        if (cc == 0) v.x = pc;
+        else if (cc == 2) v.z = pc;
+        else v.y = pc;
+        if (cc != 1) {
+          float h[7], vv[7];
+#pragma unroll
+          for (int d = -3; d <= 3; d++) {
+            h[d + 3] = ctr[d];
+            vv[d + 3] = ctr[d * RS];
+          }
+          v.y = ppg_green(h, vv);
+        }
+        v = mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
+      }
+    }
+    pr[r * GS + c] = v.x;
+    pg[r * GS + c] = v.y;
+    pb[r * GS + c] = v.z;
+  }
+  __syncthreads();
+
+  const int lx = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int ly = (threadIdx.x >> 4) + pass * 16;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= width || y >= height) continue;
+    float px[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int gx = x + k;
+      const int base = (ly + 1) * GS + (lx + k + 1);
+      f3 col = mk3(pr[base], pg[base], pb[base]);
+      if (gx < width && !(gx == 0 || y == 0 || gx == width - 1 || y == height - 1)) {
+        auto nb = [&](int dx, int dy) { const int q = base + dy * GS + dx; return mk3(pr[q], pg[q], pb[q]); };
+        col = ppg_redblue(nb, col, cfa_color(y, gx, pattern), cfa_color(y, gx + 1, pattern) == 0);
+      }
+      px[3 * k] = fmaxf(col.x, 0.0f);
+      px[3 * k + 1] = fmaxf(col.y, 0.0f);
+      px[3 * k + 2] = fmaxf(col.z, 0.0f);
+    }
+    store_rgb4(out, x, y, width, vec_ok, px);
+  }
+}
+
+// reference ppg.cu:21-113; threshold already divided by 100
+template <typename T>
+__global__ __launch_bounds__(256) void pre_median_kernel(const T* __restrict__ in, T* __restrict__ out, int width, int height,
+                                                         uint32_t pattern, float threshold) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= width || y >= height) return;
+  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < width && yy < height) ? ld(in, (size_t)yy * width + xx) : 0.0f; };
+  const float center = rd(x, y);
+  float med[9];
+  int cnt = 0;
+  {
+    constexpr int DX[9] = {0, -1, 1, -2, 0, 2, -1, 1, 0};
+    constexpr int DY[9] = {-2, -1, -1, 0, 0, 0, 1, 1, 2};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const float v = rd(x + DX[k], y + DY[k]);
+      if (fabsf(v - center) < threshold) { med[k] = v; cnt++; }
+      else med[k] = 64.0f + v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int ii = i + 1; ii < 9; ii++)
+      if (med[i] > med[ii]) { const float t = med[i]; med[i] = med[ii]; med[ii] = t; }
+  float color = center;
+  if (cfa_color(y, x, pattern) & 1) {
+    // med[(cnt - 1) / 2] with a register-resident array: select instead of dynamic indexing
+    float pick = med[0];
+    const int idx = (cnt - 1) / 2;
+#pragma unroll
+    for (int k = 1; k < 9; k++) pick = (idx == k) ? med[k] : pick;
+    const float target = (cnt == 1) ? (med[4] - 64.0f) : pick;
+    const float delta = target - center;
+    color = center + fminf(fmaxf(delta, -threshold), threshold);
+  }
+  st(out, (size_t)y * width + x, fmaxf(color, 0.0f));
+}
+
+template <typename T>
+int launch(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, float median_threshold, hipStream_t s) {
+  const T* in = reinterpret_cast<const T*>(bayer);
+  const T* src = in;
+  if (median_threshold > 0.0f) {
+    T* med = reinterpret_cast<T*>(workspace);
+    hipLaunchKernelGGL(pre_median_kernel<T>, dim3(tdk_div_up(width, 64), tdk_div_up(height, 4)), dim3(256), 0, s, in, med, width, height,
+                       pattern, median_threshold / 100.0f);
+    TDK_CHECK_LAUNCH("tdk_ppg(pre_median)");
+    src = med;
+  }
+  const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb, 16);
+  hipLaunchKernelGGL(ppg_fused<T>, dim3(tdk_div_up(width, TW), tdk_div_up(height, TH)), dim3(256), 0, s, src, in, reinterpret_cast<T*>(rgb),
+                     width, height, pattern, vec_ok);
+  TDK_CHECK_LAUNCH("tdk_ppg");
+  return TDK_OK;
+}
+
+}  // namespace
+
+TDK_EXPORT size_t tdk_ppg_workspace_bytes(int width, int height, float median_threshold) {
+  if (!(median_threshold > 0.0f) || width <= 0 || height <= 0) return 0;
+  return tdk_align_up((size_t)width * height * sizeof(float), 256);
+}
+
+TDK_EXPORT int tdk_ppg(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, float median_threshold,
+                       int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(bayer && rgb, "tdk_ppg: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "tdk_ppg: invalid size %dx%d", width, height);
+  TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
+              "tdk_ppg: invalid Bayer pattern 0x%08x", pattern);
+  TDK_REQUIRE(!(median_threshold > 0.0f) || workspace, "tdk_ppg: median_threshold > 0 needs a workspace");
+  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, workspace, width, height, pattern, median_threshold, tdk_stream(stream)));
+  return TDK_OK;
+}

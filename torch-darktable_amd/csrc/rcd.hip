@@ -1,0 +1,437 @@
+// rcd.hip -- Ratio Corrected Demosaic, fused.
+//
+// Replaces reference csrc/debayer/rcd.cu:30-681 (RCDImpl::process: 13 launches over eight
+// full-resolution fp32 scratch planes, ~150 B/px of HBM traffic).  Semantics: the reference's
+// FIRST call on a fresh workspace, as a pure function of the input (oracle/src/rcd.c restates
+// it literally):
+//   * every scratch plane starts at zero, so sites outside a step's write range read as 0;
+//   * the half-density planes are addressed with flat `idx / 2`: p/q_diff written at every odd
+//     column (row, c') and read by step 4.2 at (row-1, oc(col-1)), (row, oc(col)),
+//     (row+1, oc(col-1)+2) [P] / (row-1, oc(col-1)+2), (row, oc(col)), (row+1, oc(col-1)) [Q]
+//     with oc(c) = c | 1  (rcd.cu:157-181);
+//   * p/q slots step 4.1 does not write (c' in {1, W-3, W-1}, rows < 3 or > H-4) still hold
+//     the same call's v_diff / h_diff at flat position row*(W/2) + (c'-1)/2 of the shared
+//     buffer (rcd.cu:637-652) -- reproduced by stale_diff() below;
+//   * PQ_dir at (row+-1) is looked up through slots (col-1)/2 and (col-1)/2 + 1 (rcd.cu:199-207).
+//
+// MI355X design: one 1024-thread workgroup per 64 x 64 output tile.  The CFA tile plus a 10-px
+// halo (the dependency radius of step 5.2 back to the raw data) is read once, coalesced, into
+// LDS; the nine RCD steps then run back to back on five LDS planes (cfa | v_diff->p/q_diff |
+// h_diff->step-5.1 colour | VH_dir | lpf->PQ_dir + green@R/B) with plane-lifetime reuse, and
+// each thread finally writes four finished RGB pixels as three 16-B stores.  HBM sees the
+// compulsory 4 B/px read (+halo from L2) and 12 B/px write.  LDS: 5 x 84 x 85 x 4 B = 142.8 KB,
+// i.e. one workgroup (16 waves) per CU.  The [0,7) border ring (3x3 average + PPG-style
+// green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is a second, tiny kernel over the ring
+// pixels only.  Arithmetic: same operation order as the oracle, no FMA contraction, IEEE
+// divides -> bit-exact.
+#include "tdk_stencils.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 64, HALO = 10;
+constexpr int RW = TW + 2 * HALO, RH = TH + 2 * HALO;  // 84 x 84 working region
+constexpr int S = RW + 1;                               // LDS row stride (odd)
+constexpr int PLANE = RH * S;
+constexpr int NT = 1024;
+
+// v_diff / h_diff of the raw image at (fr, fc), or 0 outside step 1.1's range (rcd.cu:63-75)
+template <typename T>
+__device__ float diff_1_1(const T* __restrict__ in, int fr, int fc, int w, int h, bool vertical) {
+  if (fr < 3 || fr > h - 4 || fc < 3 || fc > w - 4) return 0.0f;
+  const int st = vertical ? w : 1;
+  const size_t idx = (size_t)fr * w + fc;
+  float c[7];
+#pragma unroll
+  for (int k = -3; k <= 3; k++) c[k + 3] = fmaxf(0.0f, ld(in, idx + (ptrdiff_t)k * st));
+  return sqf(c[0] - 3.0f * c[1] - c[2] + 6.0f * c[3] - c[4] - 3.0f * c[5] + c[6]);
+}
+
+// Content of the shared VP/HQ buffer at the p/q slot of odd-column site (row, col) when step
+// 4.1 did not write it.
+template <typename T>
+__device__ float stale_diff(const T* __restrict__ in, int row, int col, int w, int h, bool p_plane) {
+  const int64_t flat = (int64_t)row * (w / 2) + (col - 1) / 2;
+  return diff_1_1(in, (int)(flat / w), (int)(flat % w), w, h, p_plane);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok) {
+  extern __shared__ float lds[];
+  float* pA = lds;               // cfa
+  float* pB = lds + PLANE;       // v_diff, then p_diff at odd columns and q_diff at (odd - 1)
+  float* pC = lds + 2 * PLANE;   // h_diff, then step-5.1 colour at R/B sites
+  float* pD = lds + 3 * PLANE;   // VH_dir
+  float* pE = lds + 4 * PLANE;   // R/B sites: lpf then PQ_dir; their green partner (c ^ 1): green from step 3.1
+
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int gx0 = x0 - HALO, gy0 = y0 - HALO;  // global coords of local (0, 0); both even
+  const int rowpar0 = cfa_color(0, 0, pattern) & 1, rowpar1 = cfa_color(1, 0, pattern) & 1;
+  auto rb_par = [&](int gy) { return (gy & 1) ? rowpar1 : rowpar0; };  // column parity of the R/B sites of a row
+
+  // ---- P0: cfa = max(0, in), zero outside the image
+  for (int i = tid; i < RW * RH; i += NT) {
+    const int r = i / RW, c = i - r * RW;
+    const int gx = gx0 + c, gy = gy0 + r;
+    pA[r * S + c] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
+  }
+  __syncthreads();
+
+  // ---- P1: step 1.1 on the halo-7 region
+  {
+    constexpr int K = 7, SW = TW + 2 * K, SH = TH + 2 * K;
+    for (int i = tid; i < SW * SH; i += NT) {
+      const int rr = i / SW, cc = i - rr * SW;
+      const int r = rr + HALO - K, c = cc + HALO - K;
+      const int gx = gx0 + c, gy = gy0 + r;
+      float vd = 0.0f, hd = 0.0f;
+      if (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4) {
+        const float* a = pA + r * S + c;
+        vd = sqf(a[-3 * S] - 3.0f * a[-2 * S] - a[-S] + 6.0f * a[0] - a[S] - 3.0f * a[2 * S] + a[3 * S]);
+        hd = sqf(a[-3] - 3.0f * a[-2] - a[-1] + 6.0f * a[0] - a[1] - 3.0f * a[2] + a[3]);
+      }
+      pB[r * S + c] = vd;
+      pC[r * S + c] = hd;
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: step 1.2 (VH_dir, halo 6) and step 2.1 (lpf at R/B sites, halo 7)
+  {
+    constexpr int K = 6, SW = TW + 2 * K, SH = TH + 2 * K;
+    for (int i = tid; i < SW * SH; i += NT) {
+      const int rr = i / SW, cc = i - rr * SW;
+      const int r = rr + HALO - K, c = cc + HALO - K;
+      const int gx = gx0 + c, gy = gy0 + r;
+      float vh = 0.0f;
+      if (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3) {
+        const int q = r * S + c;
+        const float eps = 1e-10f;
+        const float V_Stat = fmaxf(eps, pB[q - S] + pB[q] + pB[q + S]);
+        const float H_Stat = fmaxf(eps, pC[q - 1] + pC[q] + pC[q + 1]);
+        vh = V_Stat / (V_Stat + H_Stat);
+      }
+      pD[r * S + c] = vh;
+    }
+  }
+  {
+    constexpr int K = 7, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
+    for (int i = tid; i < SW2 * SH; i += NT) {
+      const int rr = i / SW2, ci = i - rr * SW2;
+      const int r = rr + HALO - K;
+      const int gy = gy0 + r;
+      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
+      const int gx = gx0 + c;
+      float v = 0.0f;
+      if (gy >= 2 && gy <= h - 2 && gx >= 2 && gx <= w - 2) {
+        const float* a = pA + r * S + c;
+        v = a[0] + 0.5f * (a[-S] + a[S] + a[-1] + a[1]) + 0.25f * (a[-S - 1] + a[-S + 1] + a[S - 1] + a[S + 1]);
+      }
+      pE[r * S + c] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- P3: step 3.1 (green at R/B sites, halo 5 -> pE at the green partner) and
+  //          step 4.1 (p/q_diff at odd columns, halo 6 -> pB)
+  {
+    constexpr int K = 5, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
+    for (int i = tid; i < SW2 * SH; i += NT) {
+      const int rr = i / SW2, ci = i - rr * SW2;
+      const int r = rr + HALO - K;
+      const int gy = gy0 + r;
+      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
+      const int gx = gx0 + c;
+      float g = 0.0f;
+      if (gy >= 4 && gy <= h - 5 && gx >= 4 && gx <= w - 5) {
+        const int q = r * S + c;
+        const float* a = pA + q;
+        const float* L = pE + q;
+        const float eps = 1e-5f;
+        const float VH_c = pD[q];
+        const float VH_n = 0.25f * (pD[q - S - 1] + pD[q - S + 1] + pD[q + S - 1] + pD[q + S + 1]);
+        const float VH_Disc = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+        const float cfai = a[0];
+        const float N_Grad = eps + fabsf(a[-S] - a[S]) + fabsf(cfai - a[-2 * S]) + fabsf(a[-S] - a[-3 * S]) + fabsf(a[-2 * S] - a[-4 * S]);
+        const float S_Grad = eps + fabsf(a[S] - a[-S]) + fabsf(cfai - a[2 * S]) + fabsf(a[S] - a[3 * S]) + fabsf(a[2 * S] - a[4 * S]);
+        const float W_Grad = eps + fabsf(a[-1] - a[1]) + fabsf(cfai - a[-2]) + fabsf(a[-1] - a[-3]) + fabsf(a[-2] - a[-4]);
+        const float E_Grad = eps + fabsf(a[1] - a[-1]) + fabsf(cfai - a[2]) + fabsf(a[1] - a[3]) + fabsf(a[2] - a[4]);
+        const float lpfi = L[0];
+        const float N_Est = a[-S] * (lpfi + lpfi) / (eps + lpfi + L[-2 * S]);
+        const float S_Est = a[S] * (lpfi + lpfi) / (eps + lpfi + L[2 * S]);
+        const float W_Est = a[-1] * (lpfi + lpfi) / (eps + lpfi + L[-2]);
+        const float E_Est = a[1] * (lpfi + lpfi) / (eps + lpfi + L[2]);
+        const float V_Est = (S_Grad * N_Est + N_Grad * S_Est) / (N_Grad + S_Grad);
+        const float H_Est = (W_Grad * E_Est + E_Grad * W_Est) / (E_Grad + W_Grad);
+        g = mixf(V_Est, H_Est, VH_Disc);
+      }
+      pE[r * S + (c ^ 1)] = g;
+    }
+  }
+  {
+    constexpr int K = 6, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
+    for (int i = tid; i < SW2 * SH; i += NT) {
+      const int rr = i / SW2, ci = i - rr * SW2;
+      const int r = rr + HALO - K;
+      const int c = (HALO - K) + 2 * ci + 1;  // odd local column == odd global column
+      const int gx = gx0 + c, gy = gy0 + r;
+      float pd = 0.0f, qd = 0.0f;
+      if (gx >= 0 && gy >= 0 && gx < w && gy < h) {
+        if (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4) {
+          const float* a = pA + r * S + c;
+          pd = sqf((a[-3 * S - 3] - a[-S - 1] - a[S + 1] + a[3 * S + 3]) - 3.0f * (a[-2 * S - 2] + a[2 * S + 2]) + 6.0f * a[0]);
+          qd = sqf((a[-3 * S + 3] - a[-S + 1] - a[S - 1] + a[3 * S - 3]) - 3.0f * (a[-2 * S + 2] + a[2 * S - 2]) + 6.0f * a[0]);
+        } else {
+          pd = stale_diff(in, gy, gx, w, h, true);
+          qd = stale_diff(in, gy, gx, w, h, false);
+        }
+      }
+      pB[r * S + c] = pd;
+      pB[r * S + c - 1] = qd;
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: step 4.2 (PQ_dir at R/B sites, halo 4 -> pE, replacing lpf)
+  {
+    constexpr int K = 4, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
+    for (int i = tid; i < SW2 * SH; i += NT) {
+      const int rr = i / SW2, ci = i - rr * SW2;
+      const int r = rr + HALO - K;
+      const int gy = gy0 + r;
+      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
+      const int gx = gx0 + c;
+      float pq = 0.0f;
+      if (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3) {
+        const int oc0 = c | 1, ocm = (c - 1) | 1;  // odd-column aliases of col and col-1 (local parity == global parity)
+        const float eps = 1e-10f;
+        const float P_Stat = fmaxf(eps, pB[(r - 1) * S + ocm] + pB[r * S + oc0] + pB[(r + 1) * S + ocm + 2]);
+        const float Q_Stat = fmaxf(eps, pB[(r - 1) * S + ocm + 2 - 1] + pB[r * S + oc0 - 1] + pB[(r + 1) * S + ocm - 1]);
+        pq = P_Stat / (P_Stat + Q_Stat);
+      }
+      pE[r * S + c] = pq;
+    }
+  }
+  __syncthreads();
+
+  // ---- P5: step 5.1 (opposite colour at R/B sites, halo 3 -> pC)
+  {
+    constexpr int K = 3, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
+    for (int i = tid; i < SW2 * SH; i += NT) {
+      const int rr = i / SW2, ci = i - rr * SW2;
+      const int r = rr + HALO - K;
+      const int gy = gy0 + r;
+      const int par = rb_par(gy);
+      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ par);
+      const int gx = gx0 + c;
+      float val = 0.0f;
+      if (gy >= 4 && gy <= h - 4 && gx >= 4 && gx <= w - 4) {
+        const int q = r * S + c;
+        const float* a = pA + q;  // rgbc at the diagonal neighbours is their native sample
+        // green plane: own site and same-class sites keep their partner parity; the diagonal
+        // (other-class) sites sit on rows of opposite parity -> partner = column ^ 1 there too
+        auto G = [&](int dr, int dc) { return pE[(r + dr) * S + ((c + dc) ^ 1)]; };
+        // PQ_dir of row r+-1 through slots (col-1)/2 and (col-1)/2 + 1: R/B column of that row = 2*slot + parity(row+-1)
+        const int parn = par ^ 1;  // rows r-1 and r+1 hold the other R/B class
+        const int slot_c = ((c - 1) & ~1) + parn;  // local column of slot (col-1)/2 on the neighbour rows
+        const float eps = 1e-5f;
+        const float PQ_c = pE[q];
+        const float PQ_n = 0.25f * (pE[(r - 1) * S + slot_c] + pE[(r - 1) * S + slot_c + 2] + pE[(r + 1) * S + slot_c] + pE[(r + 1) * S + slot_c + 2]);
+        const float PQ_Disc = (fabsf(0.5f - PQ_c) < fabsf(0.5f - PQ_n)) ? PQ_n : PQ_c;
+        const float g0 = G(0, 0);
+        const float NW_Grad = eps + fabsf(a[-S - 1] - a[S + 1]) + fabsf(a[-S - 1] - a[-3 * S - 3]) + fabsf(g0 - G(-2, -2));
+        const float NE_Grad = eps + fabsf(a[-S + 1] - a[S - 1]) + fabsf(a[-S + 1] - a[-3 * S + 3]) + fabsf(g0 - G(-2, 2));
+        const float SW_Grad = eps + fabsf(a[-S + 1] - a[S - 1]) + fabsf(a[S - 1] - a[3 * S - 3]) + fabsf(g0 - G(2, -2));
+        const float SE_Grad = eps + fabsf(a[-S - 1] - a[S + 1]) + fabsf(a[S + 1] - a[3 * S + 3]) + fabsf(g0 - G(2, 2));
+        const float NW_Est = a[-S - 1] - G(-1, -1);
+        const float NE_Est = a[-S + 1] - G(-1, 1);
+        const float SW_Est = a[S - 1] - G(1, -1);
+        const float SE_Est = a[S + 1] - G(1, 1);
+        const float P_Est = (NW_Grad * SE_Est + SE_Grad * NW_Est) / (NW_Grad + SE_Grad);
+        const float Q_Est = (NE_Grad * SW_Est + SW_Grad * NE_Est) / (NE_Grad + SW_Grad);
+        val = g0 + mixf(P_Est, Q_Est, PQ_Disc);
+      }
+      pC[r * S + c] = val;
+    }
+  }
+  __syncthreads();
+
+  // ---- P6: step 5.2 at green sites + write_output (margin 7)
+  {
+    const int lx = (tid & 15) * 4, ly = tid >> 4;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < w && y >= 7 && y < h - 7) {
+      const int r = ly + HALO;
+      const int par = rb_par(y);
+      const int row_color = cfa_color(y, par, pattern);  // colour of this row's R/B sites (0 or 2)
+      float px[12];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int gx = x + k;
+        const int c = lx + k + HALO;
+        const int q = r * S + c;
+        float R, G, B;
+        if ((gx & 1) == par) {  // R/B site
+          const float native = pA[q], green = pE[r * S + (c ^ 1)], other = pC[q];
+          G = green;
+          if (row_color == 0) { R = native; B = other; } else { B = native; R = other; }
+        } else {  // green site: step 5.2
+          const float eps = 1e-5f;
+          const float VH_c = pD[q];
+          const float VH_n = 0.25f * (pD[q - S - 1] + pD[q - S + 1] + pD[q + S - 1] + pD[q + S + 1]);
+          const float VH_Disc = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+          const float g = pA[q];
+          const float N1 = eps + fabsf(g - pA[q - 2 * S]);
+          const float S1 = eps + fabsf(g - pA[q + 2 * S]);
+          const float W1 = eps + fabsf(g - pA[q - 2]);
+          const float E1 = eps + fabsf(g - pA[q + 2]);
+          // green at the four R/B neighbours (stored at their partner column)
+          const float gN = pE[(r - 1) * S + (c ^ 1)], gS = pE[(r + 1) * S + (c ^ 1)];
+          const float gW = pE[r * S + ((c - 1) ^ 1)], gE = pE[r * S + ((c + 1) ^ 1)];
+          // colour `row_color` is native left/right (this row's R/B sites) and from step 5.1
+          // above/below; the other colour the other way round.
+          float res[2];
+#pragma unroll
+          for (int ci = 0; ci < 2; ci++) {
+            const int col = ci * 2;  // rgbc = rgb0 then rgb2 (rcd.cu:256-258)
+            const bool native_h = (col == row_color);
+            const float* ph = native_h ? pA : pC;  // horizontal neighbours
+            const float* pv = native_h ? pC : pA;  // vertical neighbours
+            const float cN = pv[q - S], cS = pv[q + S], cW = ph[q - 1], cE = ph[q + 1];
+            const float cN3 = pv[q - 3 * S], cS3 = pv[q + 3 * S], cW3 = ph[q - 3], cE3 = ph[q + 3];
+            const float SNabs = fabsf(cN - cS);
+            const float EWabs = fabsf(cW - cE);
+            const float N_Grad = N1 + SNabs + fabsf(cN - cN3);
+            const float S_Grad = S1 + SNabs + fabsf(cS - cS3);
+            const float W_Grad = W1 + EWabs + fabsf(cW - cW3);
+            const float E_Grad = E1 + EWabs + fabsf(cE - cE3);
+            const float N_Est = cN - gN;
+            const float S_Est = cS - gS;
+            const float W_Est = cW - gW;
+            const float E_Est = cE - gE;
+            const float V_Est = (N_Grad * S_Est + S_Grad * N_Est) / (N_Grad + S_Grad);
+            const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
+            res[ci] = g + mixf(V_Est, H_Est, VH_Disc);
+          }
+          R = res[0]; G = g; B = res[1];
+        }
+        px[3 * k] = fmaxf(R, 0.0f);
+        px[3 * k + 1] = fmaxf(G, 0.0f);
+        px[3 * k + 2] = fmaxf(B, 0.0f);
+        any |= (gx >= 7 && gx < w - 7);
+      }
+      if (any) {
+        const bool all_in = (x >= 7) && (x + 3 < w - 7);
+        if (all_in) {
+          store_rgb4(out, x, y, w, vec_ok, px);
+        } else {
+          for (int k = 0; k < 4; k++) {
+            const int gx = x + k;
+            if (gx >= 7 && gx < w - 7) {
+              const size_t p = (size_t)y * w + gx;
+              st(out, p * 3, px[3 * k]); st(out, p * 3 + 1, px[3 * k + 1]); st(out, p * 3 + 2, px[3 * k + 2]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- border ring [0, 7)
+// Intermediate image of the reference's border path at (x, y): ring < 3 -> 3x3 same-colour
+// average (ppg.cu:342-389); otherwise native sample + PPG-style green (rcd.cu:285-385).
+template <typename T>
+__device__ f3 border_temp(const T* __restrict__ in, int x, int y, int w, int h, uint32_t pattern) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return mk3(0.0f, 0.0f, 0.0f);
+  if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3)
+    return border_average([&](int xx, int yy) { return ld(in, (size_t)yy * w + xx); }, x, y, w, h, pattern);
+  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? fmaxf(0.0f, ld(in, (size_t)yy * w + xx)) : 0.0f; };
+  const int c = cfa_color(y, x, pattern);
+  f3 v = mk3(0.0f, 0.0f, 0.0f);
+  const float pc = rd(x, y);
+  if (c == 0) v.x = pc;
+  else if (c == 2) v.z = pc;
+  else v.y = pc;
+  if (c != 1) {
+    float hx[7], vy[7];
+#pragma unroll
+    for (int d = -3; d <= 3; d++) { hx[d + 3] = rd(x + d, y); vy[d + 3] = rd(x, y + d); }
+    v.y = ppg_green(hx, vy);
+  }
+  return mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rcd_border(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern) {
+  // ring pixels: RBAND full rows (top + bottom) then CBAND columns of the middle rows
+  const int rband = min(h, 14), cband = min(w, 14);
+  const int mid_rows = max(h - 14, 0);
+  const int64_t n_rows = (int64_t)rband * w, n_cols = (int64_t)mid_rows * cband;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows + n_cols) return;
+  int x, y;
+  if (i < n_rows) {
+    const int r = (int)(i / w);
+    x = (int)(i - (int64_t)r * w);
+    y = (r < 7) ? r : h - rband + r;
+  } else {
+    const int64_t j = i - n_rows;
+    const int r = (int)(j / cband), cidx = (int)(j - (int64_t)r * cband);
+    y = 7 + r;
+    x = (cidx < 7) ? cidx : w - cband + cidx;
+  }
+  // rcd_border_redblue (rcd.cu:387-493): 3x3 neighbourhood of max(0, temp)
+  f3 nbv[3][3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+      const f3 t = border_temp(in, x + dx, y + dy, w, h, pattern);
+      nbv[dy + 1][dx + 1] = mk3(fmaxf(0.0f, t.x), fmaxf(0.0f, t.y), fmaxf(0.0f, t.z));
+    }
+  f3 col = nbv[1][1];
+  if (y > 0 && x > 0 && x < w - 1 && y < h - 1) {
+    auto nb = [&](int dx, int dy) { return nbv[dy + 1][dx + 1]; };
+    col = ppg_redblue(nb, col, cfa_color(y, x, pattern), cfa_color(y, x + 1, pattern) == 0);
+  }
+  const size_t p = (size_t)y * w + x;
+  st(out, p * 3, fmaxf(col.x, 0.0f));
+  st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
+  st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
+}
+
+template <typename T>
+int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
+  const T* in = reinterpret_cast<const T*>(bayer);
+  T* out = reinterpret_cast<T*>(rgb);
+  const int vec_ok = (w % 4 == 0) && tdk_aligned(rgb, 16);
+  constexpr size_t lds_bytes = (size_t)5 * PLANE * sizeof(float);
+  // per launch (cheap, and correct whichever device is current)
+  TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
+               "tdk_rcd(hipFuncSetAttribute)");
+  if (w > 14 && h > 14) {
+    hipLaunchKernelGGL(rcd_interior<T>, dim3(tdk_div_up(w, TW), tdk_div_up(h, TH)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok);
+    TDK_CHECK_LAUNCH("tdk_rcd(interior)");
+  }
+  const int rband = h < 14 ? h : 14, cband = w < 14 ? w : 14;
+  const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
+  hipLaunchKernelGGL(rcd_border<T>, dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
+  TDK_CHECK_LAUNCH("tdk_rcd(border)");
+  return TDK_OK;
+}
+
+}  // namespace
+
+TDK_EXPORT size_t tdk_rcd_workspace_bytes(int, int) { return 0; }
+
+TDK_EXPORT int tdk_rcd(const void* bayer, void* rgb, void* /*workspace*/, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(bayer && rgb, "tdk_rcd: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "tdk_rcd: invalid size %dx%d", width, height);
+  TDK_REQUIRE((width & 1) == 0, "tdk_rcd: width must be even (the reference packs half-density planes as idx/2)");
+  TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
+              "tdk_rcd: invalid Bayer pattern 0x%08x", pattern);
+  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, tdk_stream(stream)));
+  return TDK_OK;
+}

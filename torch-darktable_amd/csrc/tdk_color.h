@@ -1,0 +1,167 @@
+// tdk_color.h -- device colour math.  The reference carries two divergent headers that
+// define the same names; both behaviours are needed, so they live in two namespaces:
+//   cA : csrc/device_conversions.h        -> public colour ops, luminance extract / replace
+//   cB : csrc/device_color_conversions.h  -> Lab vibrance inside the tonemap kernels
+// Transcendentals are the ROCm device-library powf / cbrtf / expf / logf.
+#pragma once
+
+#include "tdk_common.h"
+
+__device__ __forceinline__ f3 clip3(f3 a) { return mk3(clip01(a.x), clip01(a.y), clip01(a.z)); }
+
+// row-major 3x3 times vector (reference csrc/device_math.h:108-114)
+__device__ __forceinline__ f3 mat3_mul(const float m[9], f3 v) {
+  return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+
+__device__ __forceinline__ f3 rgb_to_xyz_lin(f3 v) {
+  return mk3(0.4124564f * v.x + 0.3575761f * v.y + 0.1804375f * v.z, 0.2126729f * v.x + 0.7151522f * v.y + 0.0721750f * v.z,
+             0.0193339f * v.x + 0.1191920f * v.y + 0.9503041f * v.z);
+}
+__device__ __forceinline__ f3 xyz_to_rgb_lin(f3 v) {
+  return mk3(3.2404542f * v.x + -1.5371385f * v.y + -0.4985314f * v.z, -0.9692660f * v.x + 1.8760108f * v.y + 0.0415560f * v.z,
+             0.0556434f * v.x + -0.2040259f * v.y + 1.0572252f * v.z);
+}
+
+#define TDK_D65_X 0.95047f
+#define TDK_D65_Y 1.0f
+#define TDK_D65_Z 1.08883f
+
+namespace cA {  // device_conversions.h
+
+__device__ __forceinline__ float srgb_to_linear(float c) {
+  const float a = 0.055f;
+  const float lin = c * (1.0f / 12.92f);
+  return (c > 0.04045f) ? powf((c + a) / (1.0f + a), 2.4f) : lin;
+}
+__device__ __forceinline__ float linear_to_srgb(float c) {
+  const float a = 0.055f;
+  return (c > 0.0031308f) ? ((1.0f + a) * powf(c, 1.0f / 2.4f) - a) : c * 12.92f;
+}
+__device__ __forceinline__ float lab_f(float t) { return (t > 0.008856f) ? powf(t, 1.0f / 3.0f) : (t * 7.787f + 16.0f / 116.0f); }
+__device__ __forceinline__ float lab_f_inv(float t) {
+  const float t3 = t * t * t;
+  return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) / 7.787f;
+}
+__device__ __forceinline__ f3 rgb_to_xyz(f3 c) { return rgb_to_xyz_lin(mk3(srgb_to_linear(c.x), srgb_to_linear(c.y), srgb_to_linear(c.z))); }
+__device__ __forceinline__ f3 xyz_to_lab(f3 xyz) {
+  const float fx = lab_f(xyz.x / TDK_D65_X), fy = lab_f(xyz.y / TDK_D65_Y), fz = lab_f(xyz.z / TDK_D65_Z);
+  return mk3((116.0f / 100.0f) * fy - (16.0f / 100.0f), (500.0f / 128.0f) * (fx - fy), (200.0f / 128.0f) * (fy - fz));
+}
+__device__ __forceinline__ f3 lab_to_xyz(f3 lab) {
+  const float fy = lab.x * (100.0f / 116.0f) + (16.0f / 116.0f);
+  const float fx = lab.y * (128.0f / 500.0f) + fy;
+  const float fz = fy - lab.z * (128.0f / 200.0f);
+  return mk3(lab_f_inv(fx) * TDK_D65_X, lab_f_inv(fy) * TDK_D65_Y, lab_f_inv(fz) * TDK_D65_Z);
+}
+__device__ __forceinline__ f3 xyz_to_rgb(f3 xyz) {
+  const f3 l = xyz_to_rgb_lin(xyz);
+  return mk3(linear_to_srgb(l.x), linear_to_srgb(l.y), linear_to_srgb(l.z));
+}
+__device__ __forceinline__ f3 rgb_to_lab(f3 c) { return xyz_to_lab(rgb_to_xyz(c)); }
+__device__ __forceinline__ f3 lab_to_rgb(f3 c) { return xyz_to_rgb(lab_to_xyz(c)); }
+
+// device_conversions.h:197-207
+__device__ __forceinline__ float rgb_to_lab_l(f3 c) {
+  const float lx = srgb_to_linear(c.x), ly = srgb_to_linear(c.y), lz = srgb_to_linear(c.z);
+  const float y = 0.2126729f * lx + 0.7151522f * ly + 0.0721750f * lz;
+  return fmaxf(0.0f, (116.0f / 100.0f) * lab_f(y) - (16.0f / 100.0f));
+}
+// device_conversions.h:213-225 (the log variant ignores eps)
+__device__ __forceinline__ f3 modify_luminance(f3 rgb, float lum) {
+  const f3 lab = rgb_to_lab(rgb);
+  return clip3(lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, lum)), lab.y, lab.z)));
+}
+__device__ __forceinline__ f3 modify_log_luminance(f3 rgb, float log_lum) {
+  const f3 lab = rgb_to_lab(rgb);
+  return clip3(lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, expf(log_lum))), lab.y, lab.z)));
+}
+
+__device__ __forceinline__ f3 rgb_to_hsl(f3 c) {
+  const float mx = fmaxf(fmaxf(c.x, c.y), c.z), mn = fminf(fminf(c.x, c.y), c.z);
+  const float delta = mx - mn;
+  float h = 0.0f, s = 0.0f;
+  const float l = (mx + mn) * 0.5f;
+  if (delta > 1e-6f) {
+    s = (l < 0.5f) ? delta / (mx + mn) : delta / (2.0f - mx - mn);
+    if (mx == c.x) h = (c.y - c.z) / delta + (c.y < c.z ? 6.0f : 0.0f);
+    else if (mx == c.y) h = (c.z - c.x) / delta + 2.0f;
+    else h = (c.x - c.y) / delta + 4.0f;
+    h /= 6.0f;
+  }
+  return mk3(h, s, l);
+}
+__device__ __forceinline__ float hsl_hue(float p, float q, float t) {
+  if (t < 0.0f) t += 1.0f;
+  if (t > 1.0f) t -= 1.0f;
+  if (t < 1.0f / 6.0f) return p + (q - p) * 6.0f * t;
+  if (t < 1.0f / 2.0f) return q;
+  if (t < 2.0f / 3.0f) return p + (q - p) * (2.0f / 3.0f - t) * 6.0f;
+  return p;
+}
+__device__ __forceinline__ f3 hsl_to_rgb(f3 hsl) {
+  const float h = hsl.x, s = hsl.y, l = hsl.z;
+  if (s < 1e-6f) return mk3(l, l, l);
+  const float q = (l < 0.5f) ? l * (1.0f + s) : l + s - l * s;
+  const float p = 2.0f * l - q;
+  return mk3(hsl_hue(p, q, h + 1.0f / 3.0f), hsl_hue(p, q, h), hsl_hue(p, q, h - 1.0f / 3.0f));
+}
+__device__ __forceinline__ f3 modify_hsl(f3 rgb, float hue, float sat, float lum) {
+  const f3 hsl = rgb_to_hsl(rgb);
+  float nh = hsl.x + hue;
+  if (nh < 0.0f) nh += 1.0f;
+  if (nh > 1.0f) nh -= 1.0f;
+  const float ns = powf(hsl.y, 1.0f / (1.0f + sat));
+  const float nl = powf(hsl.z, 1.0f / (1.0f + lum));
+  return clip3(hsl_to_rgb(mk3(nh, ns, nl)));
+}
+__device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
+  const f3 lab = rgb_to_lab(rgb);
+  const float chroma = sqrtf(lab.y * lab.y + lab.z * lab.z);
+  const float ls = 1.0f - amount * chroma * 0.25f;
+  const float ss = 1.0f + amount * chroma;
+  return clip3(lab_to_rgb(mk3(lab.x * ls, lab.y * ss, lab.z * ss)));
+}
+
+}  // namespace cA
+
+namespace cB {  // device_color_conversions.h
+
+__device__ __forceinline__ float linear_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float lab_f(float t) {
+  const float delta = 6.0f / 29.0f;
+  const float delta_cubed = delta * delta * delta;
+  const float factor = 1.0f / (3.0f * delta * delta);
+  const float offset = 4.0f / 29.0f;
+  return (t > delta_cubed) ? cbrtf(t) : factor * t + offset;
+}
+__device__ __forceinline__ float lab_f_inv(float t) {
+  const float delta = 6.0f / 29.0f;
+  const float factor = 3.0f * delta * delta;
+  const float offset = 4.0f / 29.0f;
+  return (t > delta) ? (t * t * t) : factor * (t - offset);
+}
+__device__ __forceinline__ f3 rgb_to_lab(f3 c) {
+  const f3 xyz = rgb_to_xyz_lin(mk3(srgb_to_linear(c.x), srgb_to_linear(c.y), srgb_to_linear(c.z)));
+  const float fx = lab_f(xyz.x / TDK_D65_X), fy = lab_f(xyz.y / TDK_D65_Y), fz = lab_f(xyz.z / TDK_D65_Z);
+  const float L = 116.0f * fy - 16.0f, a = 500.0f * (fx - fy), b = 200.0f * (fy - fz);
+  return mk3(L / 100.0f, a / 128.0f, b / 128.0f);
+}
+__device__ __forceinline__ f3 lab_to_rgb(f3 lab) {
+  const float L = lab.x * 100.0f, a = lab.y * 128.0f, b = lab.z * 128.0f;
+  const float fy = (L + 16.0f) / 116.0f;
+  const float fx = a / 500.0f + fy;
+  const float fz = fy - b / 200.0f;
+  const f3 lin = xyz_to_rgb_lin(mk3(lab_f_inv(fx) * TDK_D65_X, lab_f_inv(fy) * TDK_D65_Y, lab_f_inv(fz) * TDK_D65_Z));
+  return mk3(linear_to_srgb(lin.x), linear_to_srgb(lin.y), linear_to_srgb(lin.z));
+}
+__device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
+  const f3 lab = rgb_to_lab(rgb);
+  const float chroma = sqrtf(lab.y * lab.y + lab.z * lab.z);
+  const float ls = 1.0f - amount * chroma * 0.25f;
+  const float ss = 1.0f + amount * chroma;
+  return clip3(lab_to_rgb(mk3(lab.x * ls, lab.y * ss, lab.z * ss)));
+}
+
+}  // namespace cB

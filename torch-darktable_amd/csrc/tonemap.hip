@@ -1,0 +1,300 @@
+// tonemap.hip -- image statistics (bounds, metrics) and the four tonemap operators.
+//
+// Replaces reference csrc/tonemap/color_adaption.cu:12-166 (compute_bounds_kernel,
+// compute_metrics_kernel and their hosts), reinhard.cu:17-81, aces.cu:13-154, linear.cu:13-76;
+// adaptation math color_adaption.h:17-76; vibrance / Lab from tdk_color.h namespace cB
+// (the reference's device_color_conversions.h); u8 store device_math.h:347-349.
+//
+// MI355X design
+//  * statistics: one sample per thread on the stride grid, wave64 __shfl_xor reduction, one LDS
+//    slot per wave, ONE atomic per workgroup and statistic (the reference issues one atomic per
+//    warp per statistic).  The result stays on the device: the normalisation by the valid count
+//    is a 1-thread kernel, not a host .item() (color_adaption.cu:162).
+//  * tonemaps: streaming, four pixels (48 B in, 12 B out) per thread, per-image constants
+//    (map_key, exposure) hoisted out of the pixel loop; dtype-templated input (fp32 / fp16).
+#include <float.h>
+
+#include "tdk_color.h"
+
+namespace {
+
+// ------------------------------------------------------------------ bounds
+__global__ void bounds_init_kernel(float* bounds) {
+  bounds[0] = FLT_MAX;
+  bounds[1] = -FLT_MAX;
+}
+
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *a, assumed;
+  do {
+    assumed = old;
+    const float cur = __uint_as_float(assumed);
+    const float nv = fminf(v, cur);
+    if (__float_as_uint(nv) == assumed) break;
+    old = atomicCAS(a, assumed, __float_as_uint(nv));
+  } while (assumed != old);
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *a, assumed;
+  do {
+    assumed = old;
+    const float cur = __uint_as_float(assumed);
+    const float nv = fmaxf(v, cur);
+    if (__float_as_uint(nv) == assumed) break;
+    old = atomicCAS(a, assumed, __float_as_uint(nv));
+  } while (assumed != old);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bounds_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
+                                                     float* __restrict__ bounds) {
+  __shared__ float smin[4], smax[4];
+  const int64_t n = (int64_t)sw * sh;
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int sy = (int)(i / sw), sx = (int)(i - (int64_t)sy * sw);
+    const size_t p = ((size_t)(sy * stride) * width + (size_t)sx * stride) * 3;
+    const float r = ld(img, p), g = ld(img, p + 1), b = ld(img, p + 2);
+    lo = fminf(lo, fminf(fminf(r, g), b));
+    hi = fmaxf(hi, fmaxf(fmaxf(r, g), b));
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smin[wave] = lo; smax[wave] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_min_f32(&bounds[0], fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])));
+    atomic_max_f32(&bounds[1], fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+  }
+}
+
+// ------------------------------------------------------------------ metrics
+__global__ void metrics_init_kernel(float* acc) {
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0.0f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
+                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc) {
+  __shared__ float part[4][6];
+  const int64_t n = (int64_t)sw * sh;
+  const float b0 = bounds[0];
+  const float range = bounds[1] - b0 + 1e-6f;
+  float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int sy = (int)(i / sw), sx = (int)(i - (int64_t)sy * sw);
+    const size_t p = ((size_t)(sy * stride) * width + (size_t)sx * stride) * 3;
+    const float r = (ld(img, p) - b0) / range, g = (ld(img, p + 1) - b0) / range, b = (ld(img, p + 2) - b0) / range;
+    const float mask = (r >= 0.99f || g >= 0.99f || b >= 0.99f) ? 0.0f : 1.0f;
+    const float gray = r * 0.299f + g * 0.587f + b * 0.114f;
+    const float log_gray = logf(fmaxf(gray, min_gray));
+    s[0] += log_gray * mask;
+    s[1] += gray * mask;
+    s[2] += r * mask;
+    s[3] += g * mask;
+    s[4] += b * mask;
+    s[5] += mask;
+  }
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) atomicAdd(&acc[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// color_adaption.cu:161-165
+__global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __restrict__ metrics) {
+  if (threadIdx.x < 5) {
+    const float norm = 1.0f / fmaxf(acc[5], 1.0f);
+    metrics[threadIdx.x] = acc[threadIdx.x] * norm;
+  }
+}
+
+// ------------------------------------------------------------------ tonemaps
+// color_adaption.h:17-29
+__device__ __forceinline__ float map_key_of(float log_mean) {
+  const float normalized = fmaxf(0.0f, fminf(1.0f, (-log_mean) / 9.21034f));
+  return 0.3f + 0.7f * powf(normalized, 1.4f);
+}
+// aces.cu:13-34
+__device__ __forceinline__ float rrt_odt(float v) {
+  const float a = v * (v + 0.0245786f) - 0.000090537f;
+  const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+  return a / b;
+}
+__device__ __forceinline__ f3 aces_fit(f3 c) {
+  const f3 a = mk3(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z,
+                   0.02840f * c.x + 0.13383f * c.y + 0.83777f * c.z);
+  const f3 r = mk3(rrt_odt(a.x), rrt_odt(a.y), rrt_odt(a.z));
+  return mk3(1.60475f * r.x + -0.53108f * r.y + -0.07367f * r.z, -0.10208f * r.x + 1.10813f * r.y + -0.00605f * r.z,
+             -0.00327f * r.x + -0.07276f * r.y + 1.07602f * r.z);
+}
+// device_math.h:347-349
+__device__ __forceinline__ uint32_t to_u8(float x) { return (uint32_t)fminf(roundf(x * 255.0f), 255.0f); }
+
+struct TmConst {
+  float key, exposure, m0, m1, m2, inv_gamma, vibrance, light_adapt, aces_scale;
+};
+
+template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst& k) {
+  f3 tm;
+  if constexpr (MODE == TDK_TONEMAP_ACES) {
+    tm = aces_fit(mk3(c.x * k.aces_scale, c.y * k.aces_scale, c.z * k.aces_scale));
+  } else {
+    const f3 mean = mk3(lerpf(k.light_adapt, k.m0, c.x), lerpf(k.light_adapt, k.m1, c.y), lerpf(k.light_adapt, k.m2, c.z));
+    const f3 ad = mk3(powf(mean.x / k.exposure, k.key), powf(mean.y / k.exposure, k.key), powf(mean.z / k.exposure, k.key));
+    if constexpr (MODE == TDK_TONEMAP_REINHARD) tm = mk3(c.x / (ad.x + c.x), c.y / (ad.y + c.y), c.z / (ad.z + c.z));
+    else if constexpr (MODE == TDK_TONEMAP_LINEAR) tm = mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z);
+    else tm = aces_fit(mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z));
+  }
+  const f3 g = mk3(powf(fmaxf(tm.x, 0.0f), k.inv_gamma), powf(fmaxf(tm.y, 0.0f), k.inv_gamma), powf(fmaxf(tm.z, 0.0f), k.inv_gamma));
+  f3 o = cB::vibrance(g, k.vibrance);
+  if constexpr (MODE == TDK_TONEMAP_LINEAR) o = clip3(o);
+  return o;
+}
+
+template <int MODE>
+__device__ __forceinline__ TmConst make_consts(const float* metrics, float gamma, float intensity, float light_adapt, float vibrance) {
+  TmConst k;
+  k.inv_gamma = 1.0f / gamma;
+  k.vibrance = vibrance;
+  k.light_adapt = light_adapt;
+  k.aces_scale = 1.0f; k.key = 1.0f; k.exposure = 1.0f; k.m0 = k.m1 = k.m2 = 0.0f;
+  if constexpr (MODE == TDK_TONEMAP_ACES) {
+    k.aces_scale = powf(2.0f, intensity);
+  } else {
+    k.key = map_key_of(metrics[0]);
+    k.exposure = expf(intensity);
+    k.m0 = metrics[2]; k.m1 = metrics[3]; k.m2 = metrics[4];
+  }
+  return k;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void tonemap_vec4(const T* __restrict__ in, uint32_t* __restrict__ out, int64_t ngroups,
+                                                     const float* __restrict__ metrics, float gamma, float intensity, float light_adapt,
+                                                     float vibrance) {
+  const TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    float v[12];
+    rgb4_io<T>::load(in, g, v);
+    uint32_t b[12];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const f3 o = tonemap_px<MODE>(mk3(v[3 * p], v[3 * p + 1], v[3 * p + 2]), k);
+      b[3 * p] = to_u8(o.x); b[3 * p + 1] = to_u8(o.y); b[3 * p + 2] = to_u8(o.z);
+    }
+#pragma unroll
+    for (int w = 0; w < 3; w++) out[3 * g + w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void tonemap_tail(const T* __restrict__ in, uint8_t* __restrict__ out, int64_t first, int64_t npix,
+                                                     const float* __restrict__ metrics, float gamma, float intensity, float light_adapt,
+                                                     float vibrance) {
+  const TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
+  for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const f3 o = tonemap_px<MODE>(mk3(ld(in, 3 * i), ld(in, 3 * i + 1), ld(in, 3 * i + 2)), k);
+    out[3 * i] = (uint8_t)to_u8(o.x); out[3 * i + 1] = (uint8_t)to_u8(o.y); out[3 * i + 2] = (uint8_t)to_u8(o.z);
+  }
+}
+
+inline int stream_grid(int64_t nthreads) {
+  int64_t b = tdk_div_up64(nthreads, 256);
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+template <typename T, int MODE>
+int run_tonemap(const void* rgb, uint8_t* out, int64_t npix, const float* metrics, float gamma, float intensity, float light_adapt,
+                float vibrance, hipStream_t s) {
+  const T* in = reinterpret_cast<const T*>(rgb);
+  int64_t done = 0;
+  if (tdk_aligned(in, 16) && tdk_aligned(out, 4) && npix >= 4) {
+    const int64_t ng = npix / 4;
+    hipLaunchKernelGGL((tonemap_vec4<T, MODE>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
+                       gamma, intensity, light_adapt, vibrance);
+    TDK_CHECK_LAUNCH("tdk_tonemap");
+    done = ng * 4;
+  }
+  if (done < npix) {
+    hipLaunchKernelGGL((tonemap_tail<T, MODE>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, metrics, gamma,
+                       intensity, light_adapt, vibrance);
+    TDK_CHECK_LAUNCH("tdk_tonemap");
+  }
+  return TDK_OK;
+}
+
+template <typename T>
+int dispatch_tonemap(const void* rgb, uint8_t* out, int64_t npix, int mode, const float* metrics, float gamma, float intensity,
+                     float light_adapt, float vibrance, hipStream_t s) {
+  switch (mode) {
+    case TDK_TONEMAP_REINHARD: return run_tonemap<T, TDK_TONEMAP_REINHARD>(rgb, out, npix, metrics, gamma, intensity, light_adapt, vibrance, s);
+    case TDK_TONEMAP_ACES: return run_tonemap<T, TDK_TONEMAP_ACES>(rgb, out, npix, metrics, gamma, intensity, light_adapt, vibrance, s);
+    case TDK_TONEMAP_ACES_ADAPTIVE: return run_tonemap<T, TDK_TONEMAP_ACES_ADAPTIVE>(rgb, out, npix, metrics, gamma, intensity, light_adapt, vibrance, s);
+    case TDK_TONEMAP_LINEAR: return run_tonemap<T, TDK_TONEMAP_LINEAR>(rgb, out, npix, metrics, gamma, intensity, light_adapt, vibrance, s);
+    default: tdk_set_error("tdk_tonemap: unknown mode %d", mode); return TDK_ERR_INVALID_ARGUMENT;
+  }
+}
+
+}  // namespace
+
+TDK_EXPORT int tdk_image_bounds_init(float* bounds, tdk_stream_t stream) {
+  TDK_REQUIRE(bounds, "tdk_image_bounds_init: null pointer");
+  hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(1), 0, tdk_stream(stream), bounds);
+  TDK_CHECK_LAUNCH("tdk_image_bounds_init");
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_bounds_accumulate(const void* rgb, int width, int height, int stride, float* bounds, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb && bounds, "tdk_image_bounds_accumulate: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_bounds_accumulate: invalid size/stride");
+  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
+  const int grid = stream_grid((int64_t)sw * sh);
+  TDK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bounds_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, bounds));
+  TDK_CHECK_LAUNCH("tdk_image_bounds_accumulate");
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics_init(float* acc, tdk_stream_t stream) {
+  TDK_REQUIRE(acc, "tdk_image_metrics_init: null pointer");
+  hipLaunchKernelGGL(metrics_init_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc);
+  TDK_CHECK_LAUNCH("tdk_image_metrics_init");
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics_accumulate(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds,
+                                            float* acc, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb && bounds && acc, "tdk_image_metrics_accumulate: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics_accumulate: invalid size/stride");
+  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
+  const int grid = stream_grid((int64_t)sw * sh);
+  TDK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(metrics_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc));
+  TDK_CHECK_LAUNCH("tdk_image_metrics_accumulate");
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream) {
+  TDK_REQUIRE(acc && metrics, "tdk_image_metrics_finish: null pointer");
+  hipLaunchKernelGGL(metrics_finish_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc, metrics);
+  TDK_CHECK_LAUNCH("tdk_image_metrics_finish");
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_tonemap(const void* rgb, uint8_t* out, int64_t npix, int mode, const float* metrics, float gamma, float intensity,
+                           float light_adapt, float vibrance, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(npix >= 0, "tdk_tonemap: negative pixel count");
+  if (npix == 0) return TDK_OK;
+  TDK_REQUIRE(rgb && out, "tdk_tonemap: null pointer");
+  TDK_REQUIRE(mode == TDK_TONEMAP_ACES || metrics != nullptr, "tdk_tonemap: metrics required for this mode");
+  TDK_DISPATCH_DTYPE(dtype, T, return dispatch_tonemap<T>(rgb, out, npix, mode, metrics, gamma, intensity, light_adapt, vibrance, tdk_stream(stream)));
+  return TDK_OK;
+}

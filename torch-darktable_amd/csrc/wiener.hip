@@ -1,0 +1,299 @@
+// wiener.hip -- tiled-FFT Wiener shrinkage denoiser.
+//
+// Replaces reference csrc/denoise/denoise.cu:84-364, fft.h, window.h (WienerImpl::process:
+// one K x K-thread block per tile, shuffle FFT + LDS transposes, and an overlap-add of every
+// tile into a padded image with 2 global float atomics per sample, then normalise-and-crop).
+// Semantics kept: tile origins (g - ov) * s with s = K / ov, asymmetric reflect load
+// (:118-122), per-tile mean, Gaussian analysis window (x - mean) * wf[tx] * wf[ty], forward
+// 2-D FFT (along x, then y), gain max(|X|^2 + 1e-15 - sigma^2, 0) / (|X|^2 + 1e-15) (:181-185),
+// inverse (along y then x, 1/K per pass), (y + mean * wf2d) * wi2d overlap-added, divided by
+// the accumulated wf2d * wi2d mask + 1e-15.
+//
+// MI355X design (memory-side float atomics cap at ~1.3 TB/s, so the reference's ~32 global
+// atomics per pixel cannot be kept; the op is FP32-vector bound: ~2.5 kFLOP/px at ov = 4):
+//  * a wave processes 64/K tiles at once, one tile ROW per lane: the K-point FFTs run entirely
+//    in registers (fully unrolled radix-2 DIT, immediate twiddles, no cross-lane traffic); the
+//    two transposes per direction go through a per-wave padded LDS tile;
+//  * a 256-thread workgroup owns a GT x GT group of tile origins (64 x 64 output pixels) and
+//    overlap-adds its tiles into an LDS accumulator with ds_add_f32 -- no global atomics at all;
+//  * each workgroup writes its (64 - s + K)^2 partial slab once; a second streaming kernel sums
+//    the <= 4 slabs that overlap an output pixel in a fixed order and applies the mask.  The
+//    mask is input-independent and separable (every pixel is covered by exactly ov x ov tiles):
+//    mask(x, y) = m1[x mod s] * m1[y mod s], m1[r] = sum_k wf[r + k s] * wi[r + k s], so it is
+//    never accumulated.
+//  Windows are evaluated on the host in fp64 and rounded once to fp32 (the reference uses torch
+//  fp32 ops on the GPU; both are within an ulp of each other).  This file allows FMA
+//  contraction: the reference's sums are order-nondeterministic, parity is by tolerance.
+#include <math.h>
+#include <string.h>
+
+#include "tdk_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int BS = 64;  // output pixels per workgroup edge = GT * s
+
+struct WParams {
+  float wf[32];  // analysis (FFT) window
+  float wi[32];  // synthesis (interpolation) window
+  float m1[16];  // separable mask factor, index p mod s
+};
+
+// cos/sin(2 pi k / 32), k = 0..15
+__device__ constexpr float TW_COS[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
+                                         0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.19509032201612819f,
+                                         -0.38268343236508973f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254535f,
+                                         -0.92387953251128674f, -0.98078528040323043f};
+__device__ constexpr float TW_SIN[16] = {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f,
+                                         0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f,
+                                         0.92387953251128674f, 0.83146961230254546f, 0.70710678118654757f, 0.55557023301960218f,
+                                         0.38268343236508989f, 0.19509032201612861f};
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
+constexpr int bitrev(int v, int bits) {
+  int r = 0;
+  for (int b = 0; b < bits; b++) r |= ((v >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+
+// In-register radix-2 decimation-in-time FFT of N complex points (same butterfly network as
+// the reference's shuffle FFT, fft.h:133-167).  Forward: e^{-i...}; inverse: e^{+i...}, scaled 1/N.
+template <int N, bool INV> __device__ __forceinline__ void fft_inreg(float (&re)[N], float (&im)[N]) {
+  constexpr int STAGES = ilog2(N);
+#pragma unroll
+  for (int t = 0; t < N; t++) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int r = bitrev(t, STAGES);
+    if (t < r) {
+      const float a = re[t], b = im[t];
+      re[t] = re[r]; im[t] = im[r];
+      re[r] = a; im[r] = b;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < STAGES; s++) {
+    const int step = 1 << s;
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+      if ((t & step) == 0) {
+        const int p = t | step;
+        const int k = (t & (step - 1)) * ((N / 2) >> s) * (32 / N);  // index into the 32-point table
+        const float wr = TW_COS[k], wim = INV ? TW_SIN[k] : -TW_SIN[k];
+        const float br = re[p] * wr - im[p] * wim, bi = re[p] * wim + im[p] * wr;
+        const float ar = re[t], ai = im[t];
+        re[t] = ar + br; im[t] = ai + bi;
+        re[p] = ar - br; im[p] = ai - bi;
+      }
+    }
+  }
+  if (INV) {
+#pragma unroll
+    for (int t = 0; t < N; t++) { re[t] *= (1.0f / N); im[t] *= (1.0f / N); }
+  }
+}
+
+__device__ __forceinline__ int reflect_index(int x, int limit) {
+  if (x < 0) x = -x;
+  if (x >= limit) x = 2 * limit - x - 1;
+  return x;
+}
+
+// Transpose one K x K tile held one row per lane through a padded per-wave LDS buffer.
+template <int K> __device__ __forceinline__ void transpose_tile(float (&v)[K], float* buf, int row) {
+#pragma unroll
+  for (int k = 0; k < K; k++) buf[row * (K + 1) + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = buf[k * (K + 1) + row];
+  __syncthreads();
+}
+
+// One workgroup: GT x GT tile origins of one channel -> one slab of RS x RS partial sums.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan, int s,
+                                                    int jmin, int ntile_x, int ntile_y, const float* __restrict__ sigmas, WParams prm) {
+  constexpr int TPW = 64 / K;          // tiles per wave
+  constexpr int TPB = 4 * TPW;         // tiles in flight per workgroup
+  extern __shared__ float lds[];
+  const int GT = BS / s;
+  const int RS = BS - s + K;           // slab edge
+  float* acc = lds;                    // RS * RS
+  float* tbuf = lds + RS * RS + (threadIdx.x >> 6) * (TPW * K * (K + 1));  // per-wave transpose scratch
+  const int lane = threadIdx.x & 63;
+  const int row = lane & (K - 1), slot = lane / K;
+  float* my_t = tbuf + slot * (K * (K + 1));
+
+  for (int i = threadIdx.x; i < RS * RS; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+
+  const float sigma = sigmas[chan];
+  const float sig2 = sigma * sigma;
+  const int jx0 = jmin + blockIdx.x * GT, jy0 = jmin + blockIdx.y * GT;  // first tile origin index of the group
+  const int rx0 = jx0 * s, ry0 = jy0 * s;                               // slab origin in image coordinates
+  const int ngroup = GT * GT;
+  const int wave = threadIdx.x >> 6;
+
+  for (int base = 0; base < ngroup; base += TPB) {
+    const int t = base + wave * TPW + slot;          // tile index inside the group
+    const int ty_i = t / GT, tx_i = t - ty_i * GT;
+    const bool active = (t < ngroup) && (jx0 + tx_i < jmin + ntile_x) && (jy0 + ty_i < jmin + ntile_y);
+    const int ox = (jx0 + tx_i) * s, oy = (jy0 + ty_i) * s;
+
+    float re[K], im[K];
+    float mean = 0.0f;
+    if (active) {
+      const int sy = reflect_index(oy + row, H);
+      const T* src = img + (size_t)sy * W * C + chan;
+#pragma unroll
+      for (int k = 0; k < K; k++) re[k] = ld(src, (size_t)reflect_index(ox + k, W) * C);
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; k++) sum += re[k];
+#pragma unroll
+      for (int o = K / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      mean = sum / (float)(K * K);
+      const float wy = prm.wf[row];
+#pragma unroll
+      for (int k = 0; k < K; k++) { re[k] = (re[k] - mean) * (prm.wf[k] * wy); im[k] = 0.0f; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) { re[k] = 0.0f; im[k] = 0.0f; }
+    }
+
+    fft_inreg<K, false>(re, im);            // along x
+    transpose_tile<K>(re, my_t, row);
+    transpose_tile<K>(im, my_t, row);
+    fft_inreg<K, false>(re, im);            // along y (lane = kx)
+#pragma unroll
+    for (int k = 0; k < K; k++) {           // denoise.cu:181-185
+      const float power = (re[k] * re[k] + im[k] * im[k]) + 1e-15f;
+      const float gain = fmaxf(power - sig2, 0.0f) / power;
+      re[k] *= gain; im[k] *= gain;
+    }
+    fft_inreg<K, true>(re, im);             // inverse along y
+    transpose_tile<K>(re, my_t, row);
+    transpose_tile<K>(im, my_t, row);
+    fft_inreg<K, true>(re, im);             // inverse along x (lane = y again)
+
+    if (active) {
+      const float wy = prm.wf[row], iy = prm.wi[row];
+      float* dst = acc + (oy - ry0 + row) * RS + (ox - rx0);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const float fw = prm.wf[k] * wy, iw = prm.wi[k] * iy;
+        atomicAdd(dst + k, (re[k] + mean * fw) * iw);
+      }
+    }
+  }
+  __syncthreads();
+  float* slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(RS * RS);
+  for (int i = threadIdx.x; i < RS * RS; i += 256) slab[i] = acc[i];
+}
+
+// Sum the overlapping slabs of one channel, normalise by the analytic mask, crop.
+template <typename T>
+__global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int C, int chan, int s,
+                                                     int K, int jmin, int ngx, WParams prm) {
+  const int64_t n = (int64_t)W * H;
+  const int RS = BS - s + K;
+  const int u0 = -jmin * s;  // = (ov - 1) * s: pixel 0 sits at this offset inside group 0
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    const int ux = x + u0, uy = y + u0;
+    const int gx = ux / BS, gy = uy / BS;
+    const int offx = ux - gx * BS, offy = uy - gy * BS;
+    const bool px = (offx < K - s) && gx > 0, py = (offy < K - s) && gy > 0;
+    auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RS * RS) + (size_t)oy * RS + ox]; };
+    float v = slab_at(gx, gy, offx, offy);
+    if (px) v += slab_at(gx - 1, gy, offx + BS, offy);
+    if (py) v += slab_at(gx, gy - 1, offx, offy + BS);
+    if (px && py) v += slab_at(gx - 1, gy - 1, offx + BS, offy + BS);
+    const float mask = prm.m1[x % s] * prm.m1[y % s];
+    st(out, (size_t)i * C + chan, v / (mask + 1e-15f));
+  }
+}
+
+void make_window(int K, double weight, float* w) {
+  const double half = K / 2.0, scale = weight * half * half;
+  double v[32], nrm = 0.0;
+  for (int i = 0; i < K; i++) {
+    const double r = -half + 0.5 + i;
+    v[i] = exp(-(r * r) / scale);
+    nrm += v[i] * v[i];
+  }
+  nrm = sqrt(nrm);
+  for (int i = 0; i < K; i++) w[i] = (float)(v[i] / nrm);
+}
+
+struct Geometry {
+  int s, jmin, ntx, nty, ngx, ngy, RS;
+};
+
+Geometry geometry(int W, int H, int K, int ov) {
+  Geometry g;
+  g.s = K / ov;
+  g.jmin = -(ov - 1);                                  // first origin index whose tile covers pixel 0
+  g.ntx = (W - 1) / g.s - g.jmin + 1;                  // origins jmin .. floor((W-1)/s)
+  g.nty = (H - 1) / g.s - g.jmin + 1;
+  const int GT = BS / g.s;
+  g.ngx = tdk_div_up(g.ntx, GT);
+  g.ngy = tdk_div_up(g.nty, GT);
+  g.RS = BS - g.s + K;
+  return g;
+}
+
+template <typename T, int K>
+int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
+  const Geometry g = geometry(W, H, K, ov);
+  WParams prm = {};
+  make_window(K, 0.3, prm.wf);
+  make_window(K, 0.3, prm.wi);
+  for (int r = 0; r < g.s; r++) {
+    float m = 0.0f;
+    for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
+    prm.m1[r] = m;
+  }
+  float* slabs = reinterpret_cast<float*>(workspace);
+  constexpr int TPW = 64 / K;
+  const size_t lds_bytes = ((size_t)g.RS * g.RS + 4 * TPW * K * (K + 1)) * sizeof(float);
+  TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
+               "tdk_wiener(hipFuncSetAttribute)");
+  const int64_t npix = (int64_t)W * H;
+  int64_t fin_blocks = tdk_div_up64(npix, 256);
+  if (fin_blocks > 4096) fin_blocks = 4096;
+  for (int c = 0; c < C; c++) {
+    hipLaunchKernelGGL((wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(256), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H, C, c, g.s,
+                       g.jmin, g.ntx, g.nty, sigmas, prm);
+    TDK_CHECK_LAUNCH("tdk_wiener(tiles)");
+    hipLaunchKernelGGL(wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s, K, g.jmin,
+                       g.ngx, prm);
+    TDK_CHECK_LAUNCH("tdk_wiener(finish)");
+  }
+  return TDK_OK;
+}
+
+}  // namespace
+
+TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
+  if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
+  (void)channels;  // channels are processed one after another through the same slabs
+  const Geometry g = geometry(width, height, tile_size, overlap_factor);
+  return tdk_align_up((size_t)g.ngx * g.ngy * g.RS * g.RS * sizeof(float), 256);
+}
+
+TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
+                          const float* sigmas, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(in && out && workspace && sigmas, "tdk_wiener: null pointer");
+  TDK_REQUIRE(channels == 1 || channels == 3, "input channels must be 1 or 3, got %d", channels);
+  TDK_REQUIRE(tile_size == 16 || tile_size == 32, "tile_size must be 16 or 32, got %d", tile_size);
+  TDK_REQUIRE(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8, "overlap_factor must be 2, 4, or 8");
+  TDK_REQUIRE(width >= tile_size && height >= tile_size, "tdk_wiener: image %dx%d smaller than the tile size %d (reflect padding undefined)",
+              width, height, tile_size);
+  hipStream_t s = tdk_stream(stream);
+  if (tile_size == 16) TDK_DISPATCH_DTYPE(dtype, T, return (launch<T, 16>(in, out, workspace, width, height, channels, overlap_factor, sigmas, s)));
+  TDK_DISPATCH_DTYPE(dtype, T, return (launch<T, 32>(in, out, workspace, width, height, channels, overlap_factor, sigmas, s)));
+  return TDK_OK;
+}

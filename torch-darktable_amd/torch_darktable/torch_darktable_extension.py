@@ -1,0 +1,615 @@
+"""`torch_darktable.torch_darktable_extension` for MI355X -- the op surface of the reference's
+pybind11 module (reference csrc/extension.cpp:50-248, torch_darktable_extension.pyi) bound to
+the hand-written HIP kernels in libtdk_hip.so (include/tdk_hip.h).
+
+Same names, argument order, defaults, tensor conventions (HWC float32, `(width, height)` in
+constructors) and error types (RuntimeError where the reference TORCH_CHECKs).  Differences,
+all deliberate:
+  * every op runs on the tensor's own device under a device guard and on PyTorch's CURRENT
+    stream (the reference has no guard and uses the legacy default stream for colour, codec,
+    white-balance and statistics kernels);
+  * nothing synchronises with the host: green-equilibration ratio, metrics normalisation and
+    white-balance gains stay on the device (reference: `.item()` at postprocess.cu:364,
+    color_adaption.cu:162, white_balance.cu:174);
+  * float16 image storage is accepted where noted (extension; the reference is float32-only);
+  * `RCD.process` returns a fresh tensor (the reference returns its persistent workspace
+    buffer, rcd.cu:670) and is a pure function of its input;
+  * there is no CPU path: non-GPU tensors are rejected, as in the reference.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Sequence
+
+import torch
+
+from . import _native
+from ._native import TDK_F16, TDK_F32, check, lib
+
+__all__ = [
+  'BayerPattern', 'PPG', 'RCD', 'PostProcess', 'Laplacian', 'Bilateral', 'Wiener', 'TonemapParams',
+  'encode12_u16', 'encode12_float', 'decode12_float', 'decode12_half', 'decode12_u16',
+  'compute_luminance', 'modify_luminance', 'compute_log_luminance', 'modify_log_luminance', 'modify_hsl', 'modify_vibrance',
+  'rgb_to_xyz', 'xyz_to_lab', 'lab_to_xyz', 'xyz_to_rgb', 'rgb_to_lab', 'lab_to_rgb', 'color_transform_3x3',
+  'compute_image_bounds', 'compute_image_metrics', 'reinhard_tonemap', 'aces_tonemap', 'adaptive_aces_tonemap', 'linear_tonemap',
+  'bilinear5x5_demosaic', 'apply_white_balance', 'estimate_white_balance',
+  'Jpeg', 'JpegException', 'JpegInputFormat', 'JpegSubsampling',
+]
+
+
+class BayerPattern(enum.IntEnum):
+  """reference csrc/debayer/demosaic.h:7-12"""
+
+  RGGB = 0x94949494
+  BGGR = 0x16161616
+  GRBG = 0x61616161
+  GBRG = 0x49494949
+
+
+# ------------------------------------------------------------------ helpers
+def _stream() -> C.c_void_p:
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+  return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _require(cond: bool, msg: str) -> None:
+  if not cond:
+    raise RuntimeError(msg)
+
+
+def _dtype_tag(t: torch.Tensor, what: str = 'Input') -> int:
+  if t.dtype == torch.float32:
+    return TDK_F32
+  if t.dtype == torch.float16:
+    return TDK_F16
+  raise RuntimeError(f'{what} tensor must be float32 (or float16 storage)')
+
+
+def _pattern(p) -> int:
+  if isinstance(p, enum.Enum) and not isinstance(p, BayerPattern):
+    p = p.value  # torch_darktable.bayer.BayerPattern wraps the extension enum
+  return int(BayerPattern(int(p)))
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
+  return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes > 0 else None
+
+
+def _check_rgb(image: torch.Tensor, name: str = 'image', allow_half: bool = False) -> None:
+  _require(image.is_cuda, f'{name} must be CUDA')
+  ok = image.dtype == torch.float32 or (allow_half and image.dtype == torch.float16)
+  _require(ok, f'{name} must be float32')
+  _require(image.dim() == 3 and image.size(2) == 3, f'{name} must be (H,W,3)')
+
+
+# ------------------------------------------------------------------ 12-bit codec (csrc/packed.cu:158-280)
+def _check_flat(t: torch.Tensor, dtype: torch.dtype, multiple: int, what: str) -> torch.Tensor:
+  _require(t.is_cuda, 'Input must be on CUDA device')
+  _require(t.dtype == dtype, f'Input must be {what}')
+  _require(t.dim() == 1, 'Input must be 1D tensor')
+  _require(t.size(0) % multiple == 0, 'Input length must be even' if multiple == 2 else 'Input length must be multiple of 3')
+  return t.contiguous()
+
+
+def encode12_u16(input: torch.Tensor, ids_format: bool = False) -> torch.Tensor:
+  x = _check_flat(input, torch.uint16, 2, 'uint16')
+  n = x.size(0) // 2
+  out = torch.empty(n * 3, dtype=torch.uint8, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_encode12_u16(_ptr(x), _ptr(out), n, int(ids_format), _stream()))
+  return out
+
+
+def encode12_float(input: torch.Tensor, ids_format: bool = False, scaled: bool = True) -> torch.Tensor:
+  x = _check_flat(input, torch.float32, 2, 'float32')
+  n = x.size(0) // 2
+  out = torch.empty(n * 3, dtype=torch.uint8, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_encode12_f32(_ptr(x), _ptr(out), n, int(ids_format), int(scaled), _stream()))
+  return out
+
+
+def decode12_float(input: torch.Tensor, ids_format: bool = False, scaled: bool = True) -> torch.Tensor:
+  x = _check_flat(input, torch.uint8, 3, 'uint8')
+  n = x.size(0) // 3
+  out = torch.empty(n * 2, dtype=torch.float32, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_decode12_f32(_ptr(x), _ptr(out), n, int(ids_format), int(scaled), _stream()))
+  return out
+
+
+def decode12_half(input: torch.Tensor, ids_format: bool = False, scaled: bool = True) -> torch.Tensor:
+  x = _check_flat(input, torch.uint8, 3, 'uint8')
+  n = x.size(0) // 3
+  out = torch.empty(n * 2, dtype=torch.float16, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_decode12_f16(_ptr(x), _ptr(out), n, int(ids_format), int(scaled), _stream()))
+  return out
+
+
+def decode12_u16(input: torch.Tensor, ids_format: bool = False) -> torch.Tensor:
+  x = _check_flat(input, torch.uint8, 3, 'uint8')
+  n = x.size(0) // 3
+  out = torch.empty(n * 2, dtype=torch.uint16, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_decode12_u16(_ptr(x), _ptr(out), n, int(ids_format), _stream()))
+  return out
+
+
+# ------------------------------------------------------------------ demosaic
+def _check_bayer(input: torch.Tensor) -> torch.Tensor:
+  _require(input.is_cuda, 'Input tensor must be on CUDA device')
+  _require(input.dtype in (torch.float32, torch.float16), 'Input tensor must be float32')
+  _require(input.dim() == 3, 'Input tensor must be 3D (H, W, 1)')
+  _require(input.size(2) == 1, 'Input must have single channel (raw Bayer)')
+  return input.contiguous()
+
+
+def bilinear5x5_demosaic(input: torch.Tensor, pattern) -> torch.Tensor:
+  """reference csrc/debayer/bilinear.cu:104-148"""
+  x = _check_bayer(input)
+  h, w = x.size(0), x.size(1)
+  out = torch.empty((h, w, 3), dtype=x.dtype, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_bilinear5x5(_ptr(x), _ptr(out), w, h, _pattern(pattern), _dtype_tag(x), _stream()))
+  return out
+
+
+class _Workspace:
+  """Common (device, width, height) bookkeeping of the reference's *Impl structs."""
+
+  def __init__(self, device: torch.device, width: int, height: int):
+    device = torch.device(device)
+    _require(device.type == 'cuda', f'torch_darktable ops need a GPU device, got {device}')
+    if device.index is None:
+      device = torch.device('cuda', torch.cuda.current_device())
+    self._device = device
+    self._width = int(width)
+    self._height = int(height)
+
+  @property
+  def width(self) -> int:
+    return self._width
+
+  @property
+  def height(self) -> int:
+    return self._height
+
+  def _check_size(self, input: torch.Tensor) -> None:
+    _require(input.size(0) == self._height and input.size(1) == self._width, 'Input dimensions must match workspace size')
+
+
+class PPG(_Workspace):
+  """reference csrc/debayer/ppg.cu:391-476 (extension.cpp:57-65)"""
+
+  def __init__(self, device, width: int, height: int, pattern, median_threshold: float = 0.0):
+    super().__init__(device, width, height)
+    self._pattern = _pattern(pattern)
+    self.median_threshold = float(median_threshold)
+
+  def process(self, input: torch.Tensor) -> torch.Tensor:
+    x = _check_bayer(input)
+    self._check_size(x)
+    out = torch.empty((self._height, self._width, 3), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+      ws = _workspace(lib.tdk_ppg_workspace_bytes(self._width, self._height, self.median_threshold), x.device)
+      check(lib.tdk_ppg(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._pattern, self.median_threshold, _dtype_tag(x), _stream()))
+    return out
+
+
+class RCD(_Workspace):
+  """reference csrc/debayer/rcd.cu:565-681 (extension.cpp:67-74)"""
+
+  def __init__(self, device, width: int, height: int, pattern):
+    super().__init__(device, width, height)
+    self._pattern = _pattern(pattern)
+
+  def process(self, input: torch.Tensor) -> torch.Tensor:
+    x = _check_bayer(input)
+    self._check_size(x)
+    out = torch.empty((self._height, self._width, 3), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+      check(lib.tdk_rcd(_ptr(x), _ptr(out), None, self._width, self._height, self._pattern, _dtype_tag(x), _stream()))
+    return out
+
+
+class PostProcess(_Workspace):
+  """reference csrc/debayer/postprocess.cu:264-416 (extension.cpp:77-90)"""
+
+  def __init__(self, device, width: int, height: int, pattern, color_smoothing_passes: int = 0, green_eq_local: bool = False,
+               green_eq_global: bool = False, green_eq_threshold: float = 0.04):
+    super().__init__(device, width, height)
+    self._pattern = _pattern(pattern)
+    self.color_smoothing_passes = int(color_smoothing_passes)
+    self.green_eq_local = bool(green_eq_local)
+    self.green_eq_global = bool(green_eq_global)
+    self.green_eq_threshold = float(green_eq_threshold)
+
+  def process(self, input: torch.Tensor) -> torch.Tensor:
+    _require(input.is_cuda, 'Input tensor must be on CUDA device')
+    _require(input.dtype == torch.float32, 'Input tensor must be float32')
+    _require(input.dim() == 3, 'Input tensor must be 3D (H, W, 3)')
+    _require(input.size(2) == 3, 'Input must have 3 channels (RGB)')
+    _require(input.size(0) == self._height and input.size(1) == self._width,
+             f'Input size {input.size(0)}x{input.size(1)} does not match expected {self._height}x{self._width}')
+    x = input.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      nbytes = lib.tdk_postprocess_workspace_bytes(self._width, self._height, self.color_smoothing_passes, int(self.green_eq_local),
+                                                   int(self.green_eq_global))
+      ws = _workspace(nbytes, x.device)
+      check(lib.tdk_postprocess(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._pattern, self.color_smoothing_passes,
+                                int(self.green_eq_local), int(self.green_eq_global), self.green_eq_threshold, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ white balance (csrc/white_balance.cu)
+def apply_white_balance(bayer_image: torch.Tensor, gains: torch.Tensor, pattern) -> torch.Tensor:
+  _require(bayer_image.is_cuda and bayer_image.dtype == torch.float32 and bayer_image.dim() == 2, 'bayer_image must be a float32 CUDA (H, W) tensor')
+  x = bayer_image.contiguous()
+  g = gains.to(device=x.device, dtype=torch.float32).contiguous()
+  _require(g.numel() == 3, 'gains must have 3 elements')
+  out = torch.empty_like(x)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_apply_white_balance(_ptr(x), _ptr(out), _ptr(g), x.size(1), x.size(0), _pattern(pattern), _stream()))
+  return out
+
+
+def estimate_white_balance(bayer_images: Sequence[torch.Tensor], pattern, quantile: float = 0.95, stride: int = 8) -> torch.Tensor:
+  """reference csrc/white_balance.cu:57-161.  Sample extraction is a strided tensor view and the
+  quantile / mean are torch ops on the device, as in the reference (white_balance.cu:149-161).
+  Two reference slips are NOT reproduced: it samples 2x2 cells at
+  `pos * 2` although the grid is sized by `stride`, and leaves skipped mask entries
+  uninitialised; here cell (i, j) is read at (i * stride, j * stride) and every entry is defined."""
+  if len(bayer_images) == 0:
+    raise RuntimeError('No images provided')
+  pat = BayerPattern(_pattern(pattern))
+  chroma, inten = [], []
+  for img in bayer_images:
+    _require(img.is_cuda and img.dim() == 2, 'bayer images must be CUDA (H, W) tensors')
+    h, w = img.shape
+    sh, sw = h // stride, w // stride
+    ys = torch.arange(sh - 1, device=img.device) * stride
+    xs = torch.arange(sw - 1, device=img.device) * stride
+    p00 = img[ys][:, xs]
+    p01 = img[ys][:, xs + 1]
+    p10 = img[ys + 1][:, xs]
+    p11 = img[ys + 1][:, xs + 1]
+    if pat == BayerPattern.RGGB:
+      r, g, b = p00, (p01 + p10) * 0.5, p11
+    elif pat == BayerPattern.BGGR:
+      r, g, b = p11, (p01 + p10) * 0.5, p00
+    elif pat == BayerPattern.GRBG:
+      r, g, b = p01, (p00 + p11) * 0.5, p10
+    else:
+      r, g, b = p10, (p00 + p11) * 0.5, p01
+    s = r + g + b
+    valid = torch.maximum(torch.maximum(p00, p01), torch.maximum(p10, p11)) < 1.0
+    chroma.append(torch.stack((r / s, g / s), dim=-1)[valid])
+    inten.append(s[valid])
+  chroma_all, inten_all = torch.cat(chroma), torch.cat(inten)
+  dev = bayer_images[0].device
+  if chroma_all.size(0) == 0:
+    return torch.tensor([1.0, 1.0, 1.0], device=dev)
+  bright = chroma_all[inten_all >= torch.quantile(inten_all, quantile)]
+  if bright.size(0) == 0:
+    return torch.tensor([1.0, 1.0, 1.0], device=dev)
+  m = bright.mean(0)
+  return torch.stack((m[0] / m[1], torch.tensor(1.0, device=dev), (1.0 - m[0] - m[1]) / m[1]))
+
+
+# ------------------------------------------------------------------ colour (csrc/color_conversions.cu)
+_COLOR_OPS = {'rgb_to_xyz': 0, 'xyz_to_lab': 1, 'lab_to_xyz': 2, 'xyz_to_rgb': 3, 'rgb_to_lab': 4, 'lab_to_rgb': 5,
+              'modify_hsl': 6, 'modify_vibrance': 7, 'color_transform_3x3': 8}
+
+
+def _color_op(name: str, input: torch.Tensor, params=(0.0, 0.0, 0.0), matrix: torch.Tensor | None = None) -> torch.Tensor:
+  _require(input.dtype == torch.float32, 'Input must be float32')
+  _require(input.dim() == 3 and input.size(2) == 3, 'Input must be (H, W, 3)')
+  _require(input.is_cuda, 'Input must be on CUDA device')
+  _require(input.is_contiguous(), 'Input tensor must be contiguous')
+  out = torch.empty_like(input)
+  prm = (C.c_float * 3)(*[float(p) for p in params])
+  with torch.cuda.device(input.device):
+    check(lib.tdk_color_op(_ptr(input), _ptr(out), input.size(0) * input.size(1), _COLOR_OPS[name], prm, _ptr(matrix), _stream()))
+  return out
+
+
+def rgb_to_xyz(rgb: torch.Tensor) -> torch.Tensor:
+  return _color_op('rgb_to_xyz', rgb)
+
+
+def xyz_to_lab(xyz: torch.Tensor) -> torch.Tensor:
+  return _color_op('xyz_to_lab', xyz)
+
+
+def lab_to_xyz(lab: torch.Tensor) -> torch.Tensor:
+  return _color_op('lab_to_xyz', lab)
+
+
+def xyz_to_rgb(xyz: torch.Tensor) -> torch.Tensor:
+  return _color_op('xyz_to_rgb', xyz)
+
+
+def rgb_to_lab(rgb: torch.Tensor) -> torch.Tensor:
+  return _color_op('rgb_to_lab', rgb)
+
+
+def lab_to_rgb(lab: torch.Tensor) -> torch.Tensor:
+  return _color_op('lab_to_rgb', lab)
+
+
+def modify_hsl(rgb: torch.Tensor, hue_adjust: float = 0.0, sat_adjust: float = 0.0, lum_adjust: float = 0.0) -> torch.Tensor:
+  return _color_op('modify_hsl', rgb, (hue_adjust, sat_adjust, lum_adjust))
+
+
+def modify_vibrance(rgb: torch.Tensor, amount: float = 0.0) -> torch.Tensor:
+  return _color_op('modify_vibrance', rgb, (amount, 0.0, 0.0))
+
+
+def color_transform_3x3(input: torch.Tensor, matrix_3x3: torch.Tensor) -> torch.Tensor:
+  _require(matrix_3x3.dtype == torch.float32, 'Matrix must be float32')
+  _require(matrix_3x3.dim() == 2 and matrix_3x3.size(0) == 3 and matrix_3x3.size(1) == 3, 'Matrix must be (3, 3)')
+  _require(matrix_3x3.is_cuda and matrix_3x3.is_contiguous(), 'Matrix tensor must be contiguous CUDA tensor')
+  return _color_op('color_transform_3x3', input, matrix=matrix_3x3)
+
+
+def _extract_luminance(rgb: torch.Tensor, log_mode: bool, eps: float, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+  _require(rgb.dtype in (torch.float32, torch.float16), 'Input must be float32')
+  _require(rgb.dim() == 3 and rgb.size(2) == 3, 'Input must be (H, W, 3)')
+  _require(rgb.is_cuda, 'Input must be on CUDA device')
+  _require(rgb.is_contiguous(), 'Input tensor must be contiguous')
+  out = torch.empty((rgb.size(0), rgb.size(1)), dtype=out_dtype or rgb.dtype, device=rgb.device)
+  with torch.cuda.device(rgb.device):
+    check(lib.tdk_compute_luminance(_ptr(rgb), _ptr(out), rgb.size(0) * rgb.size(1), int(log_mode), float(eps), _dtype_tag(rgb),
+                                    _dtype_tag(out), _stream()))
+  return out
+
+
+def compute_luminance(rgb: torch.Tensor) -> torch.Tensor:
+  return _extract_luminance(rgb, False, 1e-6)
+
+
+def compute_log_luminance(rgb: torch.Tensor, eps: float) -> torch.Tensor:
+  _require(eps > 0.0, 'Epsilon must be positive')
+  return _extract_luminance(rgb, True, eps)
+
+
+def _replace_luminance(rgb: torch.Tensor, lum: torch.Tensor, log_mode: bool) -> torch.Tensor:
+  _require(rgb.dtype in (torch.float32, torch.float16), 'Input1 must be float32')
+  _require(lum.dtype in (torch.float32, torch.float16), 'Input2 must be float32')
+  _require(rgb.dim() == 3 and rgb.size(2) == 3, 'Input1 must be (H, W, 3)')
+  _require(lum.dim() == 2, 'Input2 must be (H, W)')
+  _require(rgb.is_cuda and lum.is_cuda, 'Inputs must be on CUDA device')
+  _require(rgb.is_contiguous() and lum.is_contiguous(), 'Input tensors must be contiguous')
+  _require(lum.size(0) == rgb.size(0) and lum.size(1) == rgb.size(1), 'Input dimensions must match')
+  out = torch.empty_like(rgb)
+  with torch.cuda.device(rgb.device):
+    check(lib.tdk_modify_luminance(_ptr(rgb), _ptr(lum), _ptr(out), lum.numel(), int(log_mode), _dtype_tag(rgb), _dtype_tag(lum), _stream()))
+  return out
+
+
+def modify_luminance(rgb: torch.Tensor, new_luminance: torch.Tensor) -> torch.Tensor:
+  return _replace_luminance(rgb, new_luminance, False)
+
+
+def modify_log_luminance(rgb: torch.Tensor, log_luminance: torch.Tensor, eps: float) -> torch.Tensor:
+  _require(eps > 0.0, 'Epsilon must be positive')
+  return _replace_luminance(rgb, log_luminance, True)
+
+
+# ------------------------------------------------------------------ statistics + tonemaps (csrc/tonemap/)
+class TonemapParams:
+  """reference csrc/tonemap/tonemap.h:6-15"""
+
+  def __init__(self, gamma: float = 1.0, intensity: float = 0.0, light_adapt: float = 0.8, vibrance: float = 0.0):
+    self.gamma = float(gamma)
+    self.intensity = float(intensity)
+    self.light_adapt = float(light_adapt)
+    self.vibrance = float(vibrance)
+
+  def __repr__(self) -> str:
+    return f'TonemapParams(gamma={self.gamma}, intensity={self.intensity}, light_adapt={self.light_adapt}, vibrance={self.vibrance})'
+
+
+def compute_image_bounds(images: Sequence[torch.Tensor], stride: int = 8) -> torch.Tensor:
+  _require(len(images) > 0, 'images must be non-empty')
+  dev = images[0].device
+  for img in images:
+    _check_rgb(img, allow_half=True)
+  bounds = torch.empty(2, dtype=torch.float32, device=dev)
+  with torch.cuda.device(dev):
+    check(lib.tdk_image_bounds_init(_ptr(bounds), _stream()))
+    for img in images:
+      x = img.contiguous()
+      check(lib.tdk_image_bounds_accumulate(_ptr(x), x.size(1), x.size(0), int(stride), _ptr(bounds), _dtype_tag(x), _stream()))
+  return bounds
+
+
+def compute_image_metrics(images: Sequence[torch.Tensor], stride: int = 8, min_gray: float = 1e-4, rescale: bool = False) -> torch.Tensor:
+  _require(len(images) > 0, 'images must be non-empty')
+  dev = images[0].device
+  _require(dev.type == 'cuda', 'image must be CUDA')
+  bounds = compute_image_bounds(images, stride) if rescale else torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
+  acc = torch.empty(8, dtype=torch.float32, device=dev)
+  metrics = torch.empty(5, dtype=torch.float32, device=dev)
+  with torch.cuda.device(dev):
+    check(lib.tdk_image_metrics_init(_ptr(acc), _stream()))
+    for img in images:
+      x = img.contiguous()
+      check(lib.tdk_image_metrics_accumulate(_ptr(x), x.size(1), x.size(0), int(stride), float(min_gray), _ptr(bounds), _ptr(acc),
+                                             _dtype_tag(x), _stream()))
+    check(lib.tdk_image_metrics_finish(_ptr(acc), _ptr(metrics), _stream()))
+  return metrics
+
+
+def _tonemap(mode: int, image: torch.Tensor, metrics: torch.Tensor | None, params: TonemapParams) -> torch.Tensor:
+  _check_rgb(image, allow_half=True)
+  if metrics is not None:
+    _require(metrics.dtype == torch.float32 and metrics.numel() == 5, 'metrics must be 5 float32 values')
+    metrics = metrics.to(image.device).contiguous()
+  x = image.contiguous()
+  out = torch.empty((x.size(0), x.size(1), 3), dtype=torch.uint8, device=x.device)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_tonemap(_ptr(x), _ptr(out), x.size(0) * x.size(1), mode, _ptr(metrics), params.gamma, params.intensity, params.light_adapt,
+                          params.vibrance, _dtype_tag(x), _stream()))
+  return out
+
+
+def reinhard_tonemap(image: torch.Tensor, metrics: torch.Tensor, params: TonemapParams) -> torch.Tensor:
+  return _tonemap(0, image, metrics, params)
+
+
+def aces_tonemap(image: torch.Tensor, params: TonemapParams) -> torch.Tensor:
+  return _tonemap(1, image, None, params)
+
+
+def adaptive_aces_tonemap(image: torch.Tensor, metrics: torch.Tensor, params: TonemapParams) -> torch.Tensor:
+  return _tonemap(2, image, metrics, params)
+
+
+def linear_tonemap(image: torch.Tensor, metrics: torch.Tensor, params: TonemapParams) -> torch.Tensor:
+  return _tonemap(3, image, metrics, params)
+
+
+# ------------------------------------------------------------------ Wiener (csrc/denoise/denoise.cu:245-364)
+class Wiener(_Workspace):
+  def __init__(self, device, width: int, height: int, overlap_factor: int = 4, tile_size: int = 32):
+    super().__init__(device, width, height)
+    self._overlap_factor = int(overlap_factor)
+    self._tile_size = int(tile_size)
+    self._ws = None
+
+  @property
+  def overlap_factor(self) -> int:
+    return self._overlap_factor
+
+  def process(self, input: torch.Tensor, noise_sigmas: torch.Tensor) -> torch.Tensor:
+    _require(input.dim() == 3, 'expected HWC tensor')
+    _require(input.device == self._device, 'input device mismatch')
+    c = input.size(2)
+    _require(c in (1, 3), f'input channels must be 1 or 3, got {c}')
+    _require(noise_sigmas.numel() == c, 'noise_sigmas must have C elements')
+    x = input.contiguous()
+    sig = noise_sigmas.to(device=x.device, dtype=torch.float32).contiguous()
+    h, w = x.size(0), x.size(1)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      nbytes = lib.tdk_wiener_workspace_bytes(w, h, c, self._tile_size, self._overlap_factor)
+      if self._ws is None or self._ws.numel() < nbytes:
+        self._ws = _workspace(max(nbytes, 256), x.device)
+      check(lib.tdk_wiener(_ptr(x), _ptr(out), _ptr(self._ws), w, h, c, self._tile_size, self._overlap_factor, _ptr(sig), _dtype_tag(x), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ local contrast
+class Bilateral(_Workspace):
+  """reference csrc/local_contrast/bilateral.cu:252-404 (extension.cpp:111-121)"""
+
+  def __init__(self, device, width: int, height: int, sigma_s: float = 8.0, sigma_r: float = 0.1):
+    super().__init__(device, width, height)
+    _require(self._width > 0 and self._height > 0, 'Invalid dimensions')
+    self._sigma_s = float(sigma_s)
+    self._sigma_r = float(sigma_r)
+    self._ws = None
+
+  @property
+  def sigma_s(self) -> float:
+    return self._sigma_s
+
+  @sigma_s.setter
+  def sigma_s(self, v: float) -> None:
+    self._sigma_s = float(v)
+    self._ws = None
+
+  @property
+  def sigma_r(self) -> float:
+    return self._sigma_r
+
+  @sigma_r.setter
+  def sigma_r(self, v: float) -> None:
+    self._sigma_r = float(v)
+    self._ws = None
+
+  def grid_size(self) -> tuple[int, int, int]:
+    sz = (C.c_int * 3)()
+    check(lib.tdk_bilateral_grid_size(self._width, self._height, self._sigma_s, self._sigma_r, sz))
+    return tuple(sz)
+
+  def process(self, luminance: torch.Tensor, detail: float) -> torch.Tensor:
+    _require(luminance.dtype in (torch.float32, torch.float16), 'Input must be float32')
+    _require(luminance.dim() == 2, 'Input must be 2D (H,W)')
+    _require(luminance.size(0) == self._height and luminance.size(1) == self._width, 'Input shape must match (H,W)')
+    _require(luminance.is_cuda, 'Input must be CUDA tensor')
+    x = luminance.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      if self._ws is None:
+        self._ws = _workspace(lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      check(lib.tdk_bilateral(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+                              _dtype_tag(x), _stream()))
+    return out
+
+
+class Laplacian(_Workspace):
+  """reference csrc/local_contrast/laplacian.cu:392-635 (extension.cpp:94-108)"""
+
+  def __init__(self, device, width: int, height: int, num_gamma: int = 6, sigma: float = 0.2, shadows: float = 1.0,
+               highlights: float = 1.0, clarity: float = 0.0):
+    super().__init__(device, width, height)
+    if int(num_gamma) != 6:
+      raise RuntimeError(f'Unsupported gamma count: {num_gamma}')
+    self._num_gamma = 6
+    self.sigma = float(sigma)
+    self.shadows = float(shadows)
+    self.highlights = float(highlights)
+    self.clarity = float(clarity)
+    self._ws = None
+
+  def process(self, input: torch.Tensor) -> torch.Tensor:
+    _require(input.dtype == torch.float32, 'Input tensor must be float32')
+    _require(input.dim() == 2, 'Input tensor must be 2D')
+    _require(input.size(0) == self._height and input.size(1) == self._width, 'Input tensor dimensions must match workspace dimensions')
+    _require(input.is_cuda, 'Input tensor must be on CUDA device')
+    x = input.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      if self._ws is None:
+        self._ws = _workspace(lib.tdk_laplacian_workspace_bytes(self._width, self._height, self._num_gamma), x.device)
+      check(lib.tdk_laplacian(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._num_gamma, self.sigma, self.shadows,
+                              self.highlights, self.clarity, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ JPEG (out of the kernel hot path)
+class JpegException(Exception):
+  pass
+
+
+class JpegInputFormat(enum.IntEnum):
+  BGR = 3
+  RGB = 4
+  BGRI = 5
+  RGBI = 6
+
+
+class JpegSubsampling(enum.IntEnum):
+  CSS_444 = 0
+  CSS_422 = 1
+  CSS_GRAY = 6
+
+
+class Jpeg:
+  """The reference wraps nvjpeg (csrc/jpeg_encoder.cu); there is no HIP kernel to write and no
+  ROCm codec is assumed, so encoding is not part of this build (next-row 8f-4)."""
+
+  def encode(self, image, quality, input_format, subsampling, progressive):
+    raise JpegException('JPEG encoding is not available in the MI355X build (out of the kernel hot path)')
+
+  def __repr__(self) -> str:
+    return 'Jpeg'
