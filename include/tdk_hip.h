@@ -46,6 +46,13 @@ enum tdk_dtype { TDK_F32 = 0, TDK_F16 = 1 };
 int tdk_abi_version(void);
 const char* tdk_last_error(void);
 
+/* Optional per-kernel device timing (the reference's counterpart: CudaTimer, csrc/cuda_utils.h:40-85).
+ * While enabled every kernel launch is bracketed by two events on its stream.
+ * tdk_profile_report blocks until they complete, writes "name launches total_ms\n" lines
+ * (NUL-terminated, truncated to cap) and returns the bytes needed.  Enabling clears old records. */
+int tdk_profile_enable(int on);
+int64_t tdk_profile_report(char* buf, int64_t cap);
+
 /* ---- 12-bit packed raw codec: reference csrc/packed.cu:158-280 (extension.cpp:159-169).
  * Flat buffers, `num_pairs` pixel pairs <-> 3 * num_pairs bytes. */
 int tdk_encode12_u16(const uint16_t* in, uint8_t* out, int64_t num_pairs, int ids_format, tdk_stream_t stream);

@@ -200,17 +200,13 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
   const T* in = reinterpret_cast<const T*>(lum_in);
   T* out = reinterpret_cast<T*>(lum_out);
   TDK_HIP_CALL(hipMemsetAsync(grid, 0, ncell * sizeof(float), s), "tdk_bilateral(memset)");
-  hipLaunchKernelGGL(splat_kernel<T>, dim3(tdk_div_up(width, SPT), tdk_div_up(height, SPT)), dim3(256), 0, s, in, grid, width, height, d, sigma_s, sigma_r);
-  TDK_CHECK_LAUNCH("tdk_bilateral(splat)");
-  hipLaunchKernelGGL(blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);
-  TDK_CHECK_LAUNCH("tdk_bilateral(blur_xy)");
-  hipLaunchKernelGGL(blur_z_kernel, dim3((unsigned)tdk_div_up64((int64_t)d.sx * d.sy, 256)), dim3(256), 0, s, tmp, grid, d);
-  TDK_CHECK_LAUNCH("tdk_bilateral(blur_z)");
+  TDK_LAUNCH("tdk_bilateral(splat)", splat_kernel<T>, dim3(tdk_div_up(width, SPT), tdk_div_up(height, SPT)), dim3(256), 0, s, in, grid, width, height, d, sigma_s, sigma_r);
+  TDK_LAUNCH("tdk_bilateral(blur_xy)", blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);
+  TDK_LAUNCH("tdk_bilateral(blur_z)", blur_z_kernel, dim3((unsigned)tdk_div_up64((int64_t)d.sx * d.sy, 256)), dim3(256), 0, s, tmp, grid, d);
   const int64_t npix = (int64_t)width * height;
   int64_t blocks = tdk_div_up64(npix, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(slice_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, in, grid, out, width, height, d, sigma_s, sigma_r, detail);
-  TDK_CHECK_LAUNCH("tdk_bilateral(slice)");
+  TDK_LAUNCH("tdk_bilateral(slice)", slice_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, in, grid, out, width, height, d, sigma_s, sigma_r, detail);
   return TDK_OK;
 }
 

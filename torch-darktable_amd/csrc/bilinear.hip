@@ -116,13 +116,12 @@ int launch(const void* bayer, void* rgb, int width, int height, uint32_t pattern
   T* out = reinterpret_cast<T*>(rgb);
   const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb, 16);
   switch (pattern) {
-    case TDK_PATTERN_RGGB: hipLaunchKernelGGL((bilinear_kernel<T, 0>), grid, block, 0, s, in, out, width, height, vec_ok); break;
-    case TDK_PATTERN_BGGR: hipLaunchKernelGGL((bilinear_kernel<T, 1>), grid, block, 0, s, in, out, width, height, vec_ok); break;
-    case TDK_PATTERN_GRBG: hipLaunchKernelGGL((bilinear_kernel<T, 2>), grid, block, 0, s, in, out, width, height, vec_ok); break;
-    case TDK_PATTERN_GBRG: hipLaunchKernelGGL((bilinear_kernel<T, 3>), grid, block, 0, s, in, out, width, height, vec_ok); break;
+    case TDK_PATTERN_RGGB: TDK_LAUNCH("tdk_bilinear5x5", (bilinear_kernel<T, 0>), grid, block, 0, s, in, out, width, height, vec_ok); break;
+    case TDK_PATTERN_BGGR: TDK_LAUNCH("tdk_bilinear5x5", (bilinear_kernel<T, 1>), grid, block, 0, s, in, out, width, height, vec_ok); break;
+    case TDK_PATTERN_GRBG: TDK_LAUNCH("tdk_bilinear5x5", (bilinear_kernel<T, 2>), grid, block, 0, s, in, out, width, height, vec_ok); break;
+    case TDK_PATTERN_GBRG: TDK_LAUNCH("tdk_bilinear5x5", (bilinear_kernel<T, 3>), grid, block, 0, s, in, out, width, height, vec_ok); break;
     default: tdk_set_error("tdk_bilinear5x5: invalid Bayer pattern 0x%08x", pattern); return TDK_ERR_INVALID_ARGUMENT;
   }
-  TDK_CHECK_LAUNCH("tdk_bilinear5x5");
   return TDK_OK;
 }
 

@@ -142,16 +142,14 @@ int run_decode(const uint8_t* in, OUT* out, int64_t num_pairs, bool ids, float s
   if (tdk_aligned(in, 4) && tdk_aligned(out, 16)) {
     const int64_t ngroups = num_pairs / 4;
     if (ngroups > 0) {
-      hipLaunchKernelGGL(decode12_bulk<OUT>, dim3(bulk_grid(ngroups)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(in), out,
+      TDK_LAUNCH(name, decode12_bulk<OUT>, dim3(bulk_grid(ngroups)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(in), out,
                          ngroups, ids, scale);
-      TDK_CHECK_LAUNCH(name);
       done = ngroups * 4;
     }
   }
   if (done < num_pairs) {
-    hipLaunchKernelGGL(decode12_pairs<OUT>, dim3((unsigned)tdk_div_up64(num_pairs - done, 256)), dim3(256), 0, s, in, out, done,
+    TDK_LAUNCH(name, decode12_pairs<OUT>, dim3((unsigned)tdk_div_up64(num_pairs - done, 256)), dim3(256), 0, s, in, out, done,
                        num_pairs, ids, scale);
-    TDK_CHECK_LAUNCH(name);
   }
   return TDK_OK;
 }
@@ -165,16 +163,14 @@ int run_encode(const IN* in, uint8_t* out, int64_t num_pairs, bool ids, float sc
   if (tdk_aligned(out, 4) && tdk_aligned(in, 16)) {
     const int64_t ngroups = num_pairs / 4;
     if (ngroups > 0) {
-      hipLaunchKernelGGL(encode12_bulk<IN>, dim3(bulk_grid(ngroups)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ngroups,
+      TDK_LAUNCH(name, encode12_bulk<IN>, dim3(bulk_grid(ngroups)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ngroups,
                          ids, scale);
-      TDK_CHECK_LAUNCH(name);
       done = ngroups * 4;
     }
   }
   if (done < num_pairs) {
-    hipLaunchKernelGGL(encode12_pairs<IN>, dim3((unsigned)tdk_div_up64(num_pairs - done, 256)), dim3(256), 0, s, in, out, done,
+    TDK_LAUNCH(name, encode12_pairs<IN>, dim3((unsigned)tdk_div_up64(num_pairs - done, 256)), dim3(256), 0, s, in, out, done,
                        num_pairs, ids, scale);
-    TDK_CHECK_LAUNCH(name);
   }
   return TDK_OK;
 }

@@ -71,13 +71,11 @@ template <int OP> int run_color(const float* in, float* out, int64_t npix, OpArg
   int64_t done = 0;
   if (tdk_aligned(in, 16) && tdk_aligned(out, 16) && npix >= 4) {
     const int64_t ng = npix / 4;
-    hipLaunchKernelGGL(color_vec4<OP>, dim3(stream_grid(ng)), dim3(256), 0, s, in, out, ng, a);
-    TDK_CHECK_LAUNCH("tdk_color_op");
+    TDK_LAUNCH("tdk_color_op", color_vec4<OP>, dim3(stream_grid(ng)), dim3(256), 0, s, in, out, ng, a);
     done = ng * 4;
   }
   if (done < npix) {
-    hipLaunchKernelGGL(color_tail<OP>, dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, a);
-    TDK_CHECK_LAUNCH("tdk_color_op");
+    TDK_LAUNCH("tdk_color_op", color_tail<OP>, dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, a);
   }
   return TDK_OK;
 }
@@ -91,7 +89,7 @@ __global__ __launch_bounds__(256) void lum_extract_vec4(const TR* __restrict__ r
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float y = cA::rgb_to_lab_l(clip3(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2])));
-      l[k] = LOG ? logf(fmaxf(eps, y)) : y;
+      l[k] = LOG ? tdk_log(fmaxf(eps, y)) : y;
     }
     s4_io<TL>::store(lum, g, l);
   }
@@ -100,7 +98,7 @@ template <typename TR, typename TL, bool LOG>
 __global__ __launch_bounds__(256) void lum_extract_tail(const TR* __restrict__ rgb, TL* __restrict__ lum, int64_t first, int64_t npix, float eps) {
   for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
     const float y = cA::rgb_to_lab_l(clip3(mk3(ld(rgb, 3 * i), ld(rgb, 3 * i + 1), ld(rgb, 3 * i + 2))));
-    st(lum, i, LOG ? logf(fmaxf(eps, y)) : y);
+    st(lum, i, LOG ? tdk_log(fmaxf(eps, y)) : y);
   }
 }
 
@@ -136,13 +134,11 @@ int run_extract(const void* rgb_, void* lum_, int64_t npix, float eps, hipStream
   int64_t done = 0;
   if (tdk_aligned(rgb, 16) && tdk_aligned(lum, 16) && npix >= 4) {
     const int64_t ng = npix / 4;
-    hipLaunchKernelGGL((lum_extract_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, ng, eps);
-    TDK_CHECK_LAUNCH("tdk_compute_luminance");
+    TDK_LAUNCH("tdk_compute_luminance", (lum_extract_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, ng, eps);
     done = ng * 4;
   }
   if (done < npix) {
-    hipLaunchKernelGGL((lum_extract_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, done, npix, eps);
-    TDK_CHECK_LAUNCH("tdk_compute_luminance");
+    TDK_LAUNCH("tdk_compute_luminance", (lum_extract_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, done, npix, eps);
   }
   return TDK_OK;
 }
@@ -155,13 +151,11 @@ int run_modify(const void* rgb_, const void* lum_, void* out_, int64_t npix, hip
   int64_t done = 0;
   if (tdk_aligned(rgb, 16) && tdk_aligned(lum, 16) && tdk_aligned(out, 16) && npix >= 4) {
     const int64_t ng = npix / 4;
-    hipLaunchKernelGGL((lum_modify_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, out, ng);
-    TDK_CHECK_LAUNCH("tdk_modify_luminance");
+    TDK_LAUNCH("tdk_modify_luminance", (lum_modify_vec4<TR, TL, LOG>), dim3(stream_grid(ng)), dim3(256), 0, s, rgb, lum, out, ng);
     done = ng * 4;
   }
   if (done < npix) {
-    hipLaunchKernelGGL((lum_modify_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, out, done, npix);
-    TDK_CHECK_LAUNCH("tdk_modify_luminance");
+    TDK_LAUNCH("tdk_modify_luminance", (lum_modify_tail<TR, TL, LOG>), dim3(stream_grid(npix - done)), dim3(256), 0, s, rgb, lum, out, done, npix);
   }
   return TDK_OK;
 }

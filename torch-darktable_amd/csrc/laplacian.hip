@@ -189,8 +189,7 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
   auto output = [&](int l) { return base + L.pyr_elems + L.level_off[l]; };
   auto proc = [&](int k, int l) { return base + (size_t)(2 + k) * L.pyr_elems + L.level_off[l]; };
 
-  hipLaunchKernelGGL(pad_kernel, grid2(L.bw, L.bh), dim3(256), 0, s, lum_in, padded(0), width, height, L.pad, L.bw, L.bh);
-  TDK_CHECK_LAUNCH("tdk_laplacian(pad)");
+  TDK_LAUNCH("tdk_laplacian(pad)", pad_kernel, grid2(L.bw, L.bh), dim3(256), 0, s, lum_in, padded(0), width, height, L.pad, L.bw, L.bh);
 
   for (int l = 1; l < L.levels; l++) {
     const int cw = dl(L.bw, l), ch = dl(L.bh, l), fw = dl(L.bw, l - 1);
@@ -198,8 +197,7 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     f.p[0] = padded(l - 1);
     c.p[0] = (l == L.levels - 1) ? output(l) : padded(l);
     dim3 g = grid2(cw, ch);
-    hipLaunchKernelGGL(reduce_kernel, g, dim3(256), 0, s, f, c, fw, cw, ch);
-    TDK_CHECK_LAUNCH("tdk_laplacian(reduce)");
+    TDK_LAUNCH("tdk_laplacian(reduce)", reduce_kernel, g, dim3(256), 0, s, f, c, fw, cw, ch);
   }
 
   {
@@ -208,8 +206,7 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     const int64_t n = (int64_t)L.bw * L.bh;
     int64_t blocks = tdk_div_up64(n, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(curves_kernel, dim3((unsigned)blocks), dim3(256), 0, s, padded(0), outs, n, sigma, shadows, highlights, clarity);
-    TDK_CHECK_LAUNCH("tdk_laplacian(curves)");
+    TDK_LAUNCH("tdk_laplacian(curves)", curves_kernel, dim3((unsigned)blocks), dim3(256), 0, s, padded(0), outs, n, sigma, shadows, highlights, clarity);
   }
   for (int l = 1; l < L.levels; l++) {
     const int cw = dl(L.bw, l), ch = dl(L.bh, l), fw = dl(L.bw, l - 1);
@@ -217,19 +214,16 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     for (int k = 0; k < NG; k++) { f.p[k] = proc(k, l - 1); c.p[k] = proc(k, l); }
     dim3 g = grid2(cw, ch);
     g.z = NG;
-    hipLaunchKernelGGL(reduce_kernel, g, dim3(256), 0, s, f, c, fw, cw, ch);
-    TDK_CHECK_LAUNCH("tdk_laplacian(reduce6)");
+    TDK_LAUNCH("tdk_laplacian(reduce6)", reduce_kernel, g, dim3(256), 0, s, f, c, fw, cw, ch);
   }
 
   for (int l = L.levels - 2; l >= 0; l--) {
     const int pw = dl(L.bw, l), ph = dl(L.bh, l);
     CPtr6 gf, gc;
     for (int k = 0; k < NG; k++) { gf.p[k] = proc(k, l); gc.p[k] = proc(k, l + 1); }
-    hipLaunchKernelGGL(assemble_kernel, grid2(pw, ph), dim3(256), 0, s, padded(l), output(l + 1), output(l), gf, gc, pw, ph);
-    TDK_CHECK_LAUNCH("tdk_laplacian(assemble)");
+    TDK_LAUNCH("tdk_laplacian(assemble)", assemble_kernel, grid2(pw, ph), dim3(256), 0, s, padded(l), output(l + 1), output(l), gf, gc, pw, ph);
   }
 
-  hipLaunchKernelGGL(write_back_kernel, grid2(width, height), dim3(256), 0, s, output(0), lum_out, width, height, L.pad, L.bw);
-  TDK_CHECK_LAUNCH("tdk_laplacian(write_back)");
+  TDK_LAUNCH("tdk_laplacian(write_back)", write_back_kernel, grid2(width, height), dim3(256), 0, s, output(0), lum_out, width, height, L.pad, L.bw);
   return TDK_OK;
 }

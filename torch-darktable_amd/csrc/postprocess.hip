@@ -219,27 +219,22 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
 
   for (int p = 0; p < passes; p++, stage++) {
     float* dst = dst_of(stage);
-    hipLaunchKernelGGL(smoothing_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(256), 0, s, src, dst, width, height, vec_ok);
-    TDK_CHECK_LAUNCH("tdk_postprocess(color_smoothing)");
+    TDK_LAUNCH("tdk_postprocess(color_smoothing)", smoothing_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(256), 0, s, src, dst, width, height, vec_ok);
     src = dst;
   }
   if (green_eq_global) {
     float* dst = dst_of(stage++);
     const int nb = (int)(tdk_div_up64(npix, 256) < GEQ_BLOCKS ? tdk_div_up64(npix, 256) : GEQ_BLOCKS);
-    hipLaunchKernelGGL(green_sums_kernel, dim3(nb), dim3(256), 0, s, src, width, height, pattern, partial);
-    TDK_CHECK_LAUNCH("tdk_postprocess(green_sums)");
-    hipLaunchKernelGGL(green_ratio_kernel, dim3(1), dim3(256), 0, s, partial, nb, ratio);
-    TDK_CHECK_LAUNCH("tdk_postprocess(green_ratio)");
-    hipLaunchKernelGGL(green_apply_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
-    TDK_CHECK_LAUNCH("tdk_postprocess(green_apply)");
+    TDK_LAUNCH("tdk_postprocess(green_sums)", green_sums_kernel, dim3(nb), dim3(256), 0, s, src, width, height, pattern, partial);
+    TDK_LAUNCH("tdk_postprocess(green_ratio)", green_ratio_kernel, dim3(1), dim3(256), 0, s, partial, nb, ratio);
+    TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
     src = dst;
   }
   if (green_eq_local) {
     float* dst = dst_of(stage++);
     // postprocess.cu:383: threshold / 100. is evaluated in double and narrowed
-    hipLaunchKernelGGL(green_local_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern,
+    TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern,
                        (float)((double)green_eq_threshold / 100.0));
-    TDK_CHECK_LAUNCH("tdk_postprocess(green_local)");
     src = dst;
   }
   return TDK_OK;
@@ -250,8 +245,7 @@ TDK_EXPORT int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, 
   TDK_REQUIRE(bayer_in && bayer_out && gains, "tdk_apply_white_balance: null pointer");
   TDK_REQUIRE(width > 0 && height > 0, "tdk_apply_white_balance: invalid size %dx%d", width, height);
   const int64_t npix = (int64_t)width * height;
-  hipLaunchKernelGGL(white_balance_kernel, dim3(stream_grid(npix)), dim3(256), 0, tdk_stream(stream), bayer_in, bayer_out, gains, width,
+  TDK_LAUNCH("tdk_apply_white_balance", white_balance_kernel, dim3(stream_grid(npix)), dim3(256), 0, tdk_stream(stream), bayer_in, bayer_out, gains, width,
                      height, pattern);
-  TDK_CHECK_LAUNCH("tdk_apply_white_balance");
   return TDK_OK;
 }

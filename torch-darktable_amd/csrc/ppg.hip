@@ -141,15 +141,13 @@ int launch(const void* bayer, void* rgb, void* workspace, int width, int height,
   const T* src = in;
   if (median_threshold > 0.0f) {
     T* med = reinterpret_cast<T*>(workspace);
-    hipLaunchKernelGGL(pre_median_kernel<T>, dim3(tdk_div_up(width, 64), tdk_div_up(height, 4)), dim3(256), 0, s, in, med, width, height,
+    TDK_LAUNCH("tdk_ppg(pre_median)", pre_median_kernel<T>, dim3(tdk_div_up(width, 64), tdk_div_up(height, 4)), dim3(256), 0, s, in, med, width, height,
                        pattern, median_threshold / 100.0f);
-    TDK_CHECK_LAUNCH("tdk_ppg(pre_median)");
     src = med;
   }
   const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb, 16);
-  hipLaunchKernelGGL(ppg_fused<T>, dim3(tdk_div_up(width, TW), tdk_div_up(height, TH)), dim3(256), 0, s, src, in, reinterpret_cast<T*>(rgb),
+  TDK_LAUNCH("tdk_ppg", ppg_fused<T>, dim3(tdk_div_up(width, TW), tdk_div_up(height, TH)), dim3(256), 0, s, src, in, reinterpret_cast<T*>(rgb),
                      width, height, pattern, vec_ok);
-  TDK_CHECK_LAUNCH("tdk_ppg");
   return TDK_OK;
 }
 

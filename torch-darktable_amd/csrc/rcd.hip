@@ -412,13 +412,11 @@ int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStre
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_rcd(hipFuncSetAttribute)");
   if (w > 14 && h > 14) {
-    hipLaunchKernelGGL(rcd_interior<T>, dim3(tdk_div_up(w, TW), tdk_div_up(h, TH)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok);
-    TDK_CHECK_LAUNCH("tdk_rcd(interior)");
+    TDK_LAUNCH("tdk_rcd(interior)", rcd_interior<T>, dim3(tdk_div_up(w, TW), tdk_div_up(h, TH)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok);
   }
   const int rband = h < 14 ? h : 14, cband = w < 14 ? w : 14;
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
-  hipLaunchKernelGGL(rcd_border<T>, dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
-  TDK_CHECK_LAUNCH("tdk_rcd(border)");
+  TDK_LAUNCH("tdk_rcd(border)", rcd_border<T>, dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
   return TDK_OK;
 }
 

@@ -2,10 +2,34 @@
 // define the same names; both behaviours are needed, so they live in two namespaces:
 //   cA : csrc/device_conversions.h        -> public colour ops, luminance extract / replace
 //   cB : csrc/device_color_conversions.h  -> Lab vibrance inside the tonemap kernels
-// Transcendentals are the ROCm device-library powf / cbrtf / expf / logf.
+//
+// Transcendentals: the reference is built with nvcc --use_fast_math (setup.py:36), i.e. its
+// powf / expf / logf are the hardware exp2/log2 approximations, not correctly rounded libm
+// calls.  The same class of arithmetic is used here: v_log_f32 / v_exp_f32 (about 1 ulp each),
+// pow(x, y) = exp2(y * log2(x)).  Against the libm-based CPU oracle this costs a few 1e-7
+// relative (tests use 2e-5 absolute); the full-accuracy device-library calls are ~20x more
+// instructions and made every colour kernel ALU-bound (0.4 ms instead of ~0.05 ms per 12 MP
+// pass).  Define TDK_PRECISE_MATH to get the device-library versions back.
 #pragma once
 
 #include "tdk_common.h"
+
+#ifdef TDK_PRECISE_MATH
+__device__ __forceinline__ float tdk_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ float tdk_exp(float x) { return expf(x); }
+__device__ __forceinline__ float tdk_log(float x) { return logf(x); }
+__device__ __forceinline__ float tdk_cbrt(float x) { return cbrtf(x); }
+#else
+// x > 0: exp2(y * log2 x); x == 0: log2 -> -inf -> 0 for y > 0; x < 0 -> NaN (as powf for
+// non-integer y).  pow(x, 0) == 1 including x == 0 is kept by the y == 0 test.
+__device__ __forceinline__ float tdk_pow(float x, float y) {
+  const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+  return (y == 0.0f) ? 1.0f : r;
+}
+__device__ __forceinline__ float tdk_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float tdk_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float tdk_cbrt(float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 3.0f)); }
+#endif
 
 __device__ __forceinline__ f3 clip3(f3 a) { return mk3(clip01(a.x), clip01(a.y), clip01(a.z)); }
 
@@ -32,13 +56,13 @@ namespace cA {  // device_conversions.h
 __device__ __forceinline__ float srgb_to_linear(float c) {
   const float a = 0.055f;
   const float lin = c * (1.0f / 12.92f);
-  return (c > 0.04045f) ? powf((c + a) / (1.0f + a), 2.4f) : lin;
+  return (c > 0.04045f) ? tdk_pow((c + a) / (1.0f + a), 2.4f) : lin;
 }
 __device__ __forceinline__ float linear_to_srgb(float c) {
   const float a = 0.055f;
-  return (c > 0.0031308f) ? ((1.0f + a) * powf(c, 1.0f / 2.4f) - a) : c * 12.92f;
+  return (c > 0.0031308f) ? ((1.0f + a) * tdk_pow(c, 1.0f / 2.4f) - a) : c * 12.92f;
 }
-__device__ __forceinline__ float lab_f(float t) { return (t > 0.008856f) ? powf(t, 1.0f / 3.0f) : (t * 7.787f + 16.0f / 116.0f); }
+__device__ __forceinline__ float lab_f(float t) { return (t > 0.008856f) ? tdk_pow(t, 1.0f / 3.0f) : (t * 7.787f + 16.0f / 116.0f); }
 __device__ __forceinline__ float lab_f_inv(float t) {
   const float t3 = t * t * t;
   return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) / 7.787f;
@@ -74,7 +98,7 @@ __device__ __forceinline__ f3 modify_luminance(f3 rgb, float lum) {
 }
 __device__ __forceinline__ f3 modify_log_luminance(f3 rgb, float log_lum) {
   const f3 lab = rgb_to_lab(rgb);
-  return clip3(lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, expf(log_lum))), lab.y, lab.z)));
+  return clip3(lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, tdk_exp(log_lum))), lab.y, lab.z)));
 }
 
 __device__ __forceinline__ f3 rgb_to_hsl(f3 c) {
@@ -111,8 +135,8 @@ __device__ __forceinline__ f3 modify_hsl(f3 rgb, float hue, float sat, float lum
   float nh = hsl.x + hue;
   if (nh < 0.0f) nh += 1.0f;
   if (nh > 1.0f) nh -= 1.0f;
-  const float ns = powf(hsl.y, 1.0f / (1.0f + sat));
-  const float nl = powf(hsl.z, 1.0f / (1.0f + lum));
+  const float ns = tdk_pow(hsl.y, 1.0f / (1.0f + sat));
+  const float nl = tdk_pow(hsl.z, 1.0f / (1.0f + lum));
   return clip3(hsl_to_rgb(mk3(nh, ns, nl)));
 }
 __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
@@ -127,14 +151,14 @@ __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
 
 namespace cB {  // device_color_conversions.h
 
-__device__ __forceinline__ float linear_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
-__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float linear_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * tdk_pow(c, 1.0f / 2.4f) - 0.055f; }
+__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : tdk_pow((c + 0.055f) / 1.055f, 2.4f); }
 __device__ __forceinline__ float lab_f(float t) {
   const float delta = 6.0f / 29.0f;
   const float delta_cubed = delta * delta * delta;
   const float factor = 1.0f / (3.0f * delta * delta);
   const float offset = 4.0f / 29.0f;
-  return (t > delta_cubed) ? cbrtf(t) : factor * t + offset;
+  return (t > delta_cubed) ? tdk_cbrt(t) : factor * t + offset;
 }
 __device__ __forceinline__ float lab_f_inv(float t) {
   const float delta = 6.0f / 29.0f;

@@ -44,6 +44,21 @@ void tdk_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// Every kernel launch goes through TDK_LAUNCH: optional per-kernel event timing (the
+// tdk_profile_* entry points; the reference's counterpart is its CudaTimer,
+// csrc/cuda_utils.h:40-85) plus the launch-error check.
+void tdk_timer_begin(const char* name, hipStream_t s);
+void tdk_timer_end(hipStream_t s);
+extern bool g_tdk_profile_on;
+
+#define TDK_LAUNCH(name, kernel, grid, block, lds, stream, ...)                       \
+  do {                                                                                \
+    if (g_tdk_profile_on) tdk_timer_begin(name, stream);                              \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                \
+    if (g_tdk_profile_on) tdk_timer_end(stream);                                      \
+    TDK_CHECK_LAUNCH(name);                                                           \
+  } while (0)
+
 static inline int tdk_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t tdk_div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t tdk_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

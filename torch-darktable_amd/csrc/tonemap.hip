@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
     const float r = (ld(img, p) - b0) / range, g = (ld(img, p + 1) - b0) / range, b = (ld(img, p + 2) - b0) / range;
     const float mask = (r >= 0.99f || g >= 0.99f || b >= 0.99f) ? 0.0f : 1.0f;
     const float gray = r * 0.299f + g * 0.587f + b * 0.114f;
-    const float log_gray = logf(fmaxf(gray, min_gray));
+    const float log_gray = tdk_log(fmaxf(gray, min_gray));
     s[0] += log_gray * mask;
     s[1] += gray * mask;
     s[2] += r * mask;
@@ -120,7 +120,7 @@ __global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __re
 // color_adaption.h:17-29
 __device__ __forceinline__ float map_key_of(float log_mean) {
   const float normalized = fmaxf(0.0f, fminf(1.0f, (-log_mean) / 9.21034f));
-  return 0.3f + 0.7f * powf(normalized, 1.4f);
+  return 0.3f + 0.7f * tdk_pow(normalized, 1.4f);
 }
 // aces.cu:13-34
 __device__ __forceinline__ float rrt_odt(float v) {
@@ -148,12 +148,12 @@ template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst
     tm = aces_fit(mk3(c.x * k.aces_scale, c.y * k.aces_scale, c.z * k.aces_scale));
   } else {
     const f3 mean = mk3(lerpf(k.light_adapt, k.m0, c.x), lerpf(k.light_adapt, k.m1, c.y), lerpf(k.light_adapt, k.m2, c.z));
-    const f3 ad = mk3(powf(mean.x / k.exposure, k.key), powf(mean.y / k.exposure, k.key), powf(mean.z / k.exposure, k.key));
+    const f3 ad = mk3(tdk_pow(mean.x / k.exposure, k.key), tdk_pow(mean.y / k.exposure, k.key), tdk_pow(mean.z / k.exposure, k.key));
     if constexpr (MODE == TDK_TONEMAP_REINHARD) tm = mk3(c.x / (ad.x + c.x), c.y / (ad.y + c.y), c.z / (ad.z + c.z));
     else if constexpr (MODE == TDK_TONEMAP_LINEAR) tm = mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z);
     else tm = aces_fit(mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z));
   }
-  const f3 g = mk3(powf(fmaxf(tm.x, 0.0f), k.inv_gamma), powf(fmaxf(tm.y, 0.0f), k.inv_gamma), powf(fmaxf(tm.z, 0.0f), k.inv_gamma));
+  const f3 g = mk3(tdk_pow(fmaxf(tm.x, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.y, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.z, 0.0f), k.inv_gamma));
   f3 o = cB::vibrance(g, k.vibrance);
   if constexpr (MODE == TDK_TONEMAP_LINEAR) o = clip3(o);
   return o;
@@ -167,10 +167,10 @@ __device__ __forceinline__ TmConst make_consts(const float* metrics, float gamma
   k.light_adapt = light_adapt;
   k.aces_scale = 1.0f; k.key = 1.0f; k.exposure = 1.0f; k.m0 = k.m1 = k.m2 = 0.0f;
   if constexpr (MODE == TDK_TONEMAP_ACES) {
-    k.aces_scale = powf(2.0f, intensity);
+    k.aces_scale = tdk_pow(2.0f, intensity);
   } else {
     k.key = map_key_of(metrics[0]);
-    k.exposure = expf(intensity);
+    k.exposure = tdk_exp(intensity);
     k.m0 = metrics[2]; k.m1 = metrics[3]; k.m2 = metrics[4];
   }
   return k;
@@ -218,15 +218,13 @@ int run_tonemap(const void* rgb, uint8_t* out, int64_t npix, const float* metric
   int64_t done = 0;
   if (tdk_aligned(in, 16) && tdk_aligned(out, 4) && npix >= 4) {
     const int64_t ng = npix / 4;
-    hipLaunchKernelGGL((tonemap_vec4<T, MODE>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
+    TDK_LAUNCH("tdk_tonemap", (tonemap_vec4<T, MODE>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
                        gamma, intensity, light_adapt, vibrance);
-    TDK_CHECK_LAUNCH("tdk_tonemap");
     done = ng * 4;
   }
   if (done < npix) {
-    hipLaunchKernelGGL((tonemap_tail<T, MODE>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, metrics, gamma,
+    TDK_LAUNCH("tdk_tonemap", (tonemap_tail<T, MODE>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, metrics, gamma,
                        intensity, light_adapt, vibrance);
-    TDK_CHECK_LAUNCH("tdk_tonemap");
   }
   return TDK_OK;
 }
@@ -247,8 +245,7 @@ int dispatch_tonemap(const void* rgb, uint8_t* out, int64_t npix, int mode, cons
 
 TDK_EXPORT int tdk_image_bounds_init(float* bounds, tdk_stream_t stream) {
   TDK_REQUIRE(bounds, "tdk_image_bounds_init: null pointer");
-  hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(1), 0, tdk_stream(stream), bounds);
-  TDK_CHECK_LAUNCH("tdk_image_bounds_init");
+  TDK_LAUNCH("tdk_image_bounds_init", bounds_init_kernel, dim3(1), dim3(1), 0, tdk_stream(stream), bounds);
   return TDK_OK;
 }
 
@@ -257,16 +254,14 @@ TDK_EXPORT int tdk_image_bounds_accumulate(const void* rgb, int width, int heigh
   TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_bounds_accumulate: invalid size/stride");
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
   const int grid = stream_grid((int64_t)sw * sh);
-  TDK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bounds_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_bounds_accumulate", bounds_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
                                                   reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, bounds));
-  TDK_CHECK_LAUNCH("tdk_image_bounds_accumulate");
   return TDK_OK;
 }
 
 TDK_EXPORT int tdk_image_metrics_init(float* acc, tdk_stream_t stream) {
   TDK_REQUIRE(acc, "tdk_image_metrics_init: null pointer");
-  hipLaunchKernelGGL(metrics_init_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc);
-  TDK_CHECK_LAUNCH("tdk_image_metrics_init");
+  TDK_LAUNCH("tdk_image_metrics_init", metrics_init_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc);
   return TDK_OK;
 }
 
@@ -276,16 +271,14 @@ TDK_EXPORT int tdk_image_metrics_accumulate(const void* rgb, int width, int heig
   TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics_accumulate: invalid size/stride");
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
   const int grid = stream_grid((int64_t)sw * sh);
-  TDK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(metrics_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", metrics_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
                                                   reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc));
-  TDK_CHECK_LAUNCH("tdk_image_metrics_accumulate");
   return TDK_OK;
 }
 
 TDK_EXPORT int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream) {
   TDK_REQUIRE(acc && metrics, "tdk_image_metrics_finish: null pointer");
-  hipLaunchKernelGGL(metrics_finish_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc, metrics);
-  TDK_CHECK_LAUNCH("tdk_image_metrics_finish");
+  TDK_LAUNCH("tdk_image_metrics_finish", metrics_finish_kernel, dim3(1), dim3(64), 0, tdk_stream(stream), acc, metrics);
   return TDK_OK;
 }
 

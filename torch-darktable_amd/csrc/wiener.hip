@@ -81,8 +81,17 @@ template <int N, bool INV> __device__ __forceinline__ void fft_inreg(float (&re)
       if ((t & step) == 0) {
         const int p = t | step;
         const int k = (t & (step - 1)) * ((N / 2) >> s) * (32 / N);  // index into the 32-point table
-        const float wr = TW_COS[k], wim = INV ? TW_SIN[k] : -TW_SIN[k];
-        const float br = re[p] * wr - im[p] * wim, bi = re[p] * wim + im[p] * wr;
+        float br, bi;
+        if (k == 0) {            // w = 1
+          br = re[p]; bi = im[p];
+        } else if (k == 8) {     // w = -i (forward) / +i (inverse)
+          br = INV ? -im[p] : im[p];
+          bi = INV ? re[p] : -re[p];
+        } else {
+          const float wr = TW_COS[k], wim = INV ? TW_SIN[k] : -TW_SIN[k];
+          br = re[p] * wr - im[p] * wim;
+          bi = re[p] * wim + im[p] * wr;
+        }
         const float ar = re[t], ai = im[t];
         re[t] = ar + br; im[t] = ai + bi;
         re[p] = ar - br; im[p] = ai - bi;
@@ -101,14 +110,43 @@ __device__ __forceinline__ int reflect_index(int x, int limit) {
   return x;
 }
 
-// Transpose one K x K tile held one row per lane through a padded per-wave LDS buffer.
+// Transpose one K x K tile held one row per lane through a padded per-wave LDS buffer.  The
+// buffer belongs to one wave (LDS operations of a wave are processed in issue order), so no
+// workgroup barrier is needed -- only a fence that keeps the compiler from reordering.
 template <int K> __device__ __forceinline__ void transpose_tile(float (&v)[K], float* buf, int row) {
 #pragma unroll
   for (int k = 0; k < K; k++) buf[row * (K + 1) + k] = v[k];
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = buf[k * (K + 1) + row];
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Load K consecutive samples of one tile row (channel `chan` of an HWC image).  Tiles that lie
+// inside the image along x read contiguous memory (16-B vector loads when aligned); only edge
+// tiles pay for the per-sample reflect.
+template <typename T, int K>
+__device__ __forceinline__ void load_row(const T* __restrict__ row_ptr, int ox, int W, int C, int chan, float (&v)[K]) {
+  if (C == 1 && ox >= 0 && ox + K <= W) {
+    const T* p = row_ptr + ox;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k += 4) {
+        float t[4];
+        s4_io<T>::load(p, k / 4, t);
+        v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = ld(p, k);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = ld(row_ptr, (size_t)reflect_index(ox + k, W) * C + chan);
+  }
 }
 
 // One workgroup: GT x GT tile origins of one channel -> one slab of RS x RS partial sums.
@@ -120,13 +158,14 @@ __global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, f
   extern __shared__ float lds[];
   const int GT = BS / s;
   const int RS = BS - s + K;           // slab edge
-  float* acc = lds;                    // RS * RS
-  float* tbuf = lds + RS * RS + (threadIdx.x >> 6) * (TPW * K * (K + 1));  // per-wave transpose scratch
+  const int RSP = RS | 1;              // odd LDS row stride: the per-lane rows of a tile hit distinct banks
+  float* acc = lds;                    // RS rows of RSP
+  float* tbuf = lds + RS * RSP + (threadIdx.x >> 6) * (TPW * K * (K + 1));  // per-wave transpose scratch
   const int lane = threadIdx.x & 63;
   const int row = lane & (K - 1), slot = lane / K;
   float* my_t = tbuf + slot * (K * (K + 1));
 
-  for (int i = threadIdx.x; i < RS * RS; i += 256) acc[i] = 0.0f;
+  for (int i = threadIdx.x; i < RS * RSP; i += 256) acc[i] = 0.0f;
   __syncthreads();
 
   const float sigma = sigmas[chan];
@@ -146,9 +185,7 @@ __global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, f
     float mean = 0.0f;
     if (active) {
       const int sy = reflect_index(oy + row, H);
-      const T* src = img + (size_t)sy * W * C + chan;
-#pragma unroll
-      for (int k = 0; k < K; k++) re[k] = ld(src, (size_t)reflect_index(ox + k, W) * C);
+      load_row<T, K>(img + (size_t)sy * W * C, ox, W, C, chan, re);
       float sum = 0.0f;
 #pragma unroll
       for (int k = 0; k < K; k++) sum += re[k];
@@ -180,7 +217,7 @@ __global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, f
 
     if (active) {
       const float wy = prm.wf[row], iy = prm.wi[row];
-      float* dst = acc + (oy - ry0 + row) * RS + (ox - rx0);
+      float* dst = acc + (oy - ry0 + row) * RSP + (ox - rx0);
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const float fw = prm.wf[k] * wy, iw = prm.wi[k] * iy;
@@ -190,7 +227,10 @@ __global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, f
   }
   __syncthreads();
   float* slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(RS * RS);
-  for (int i = threadIdx.x; i < RS * RS; i += 256) slab[i] = acc[i];
+  for (int i = threadIdx.x; i < RS * RS; i += 256) {
+    const int r = i / RS, c = i - r * RS;
+    slab[i] = acc[r * RSP + c];
+  }
 }
 
 // Sum the overlapping slabs of one channel, normalise by the analytic mask, crop.
@@ -258,19 +298,17 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   }
   float* slabs = reinterpret_cast<float*>(workspace);
   constexpr int TPW = 64 / K;
-  const size_t lds_bytes = ((size_t)g.RS * g.RS + 4 * TPW * K * (K + 1)) * sizeof(float);
+  const size_t lds_bytes = ((size_t)g.RS * (g.RS | 1) + 4 * TPW * K * (K + 1)) * sizeof(float);
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_wiener(hipFuncSetAttribute)");
   const int64_t npix = (int64_t)W * H;
   int64_t fin_blocks = tdk_div_up64(npix, 256);
   if (fin_blocks > 4096) fin_blocks = 4096;
   for (int c = 0; c < C; c++) {
-    hipLaunchKernelGGL((wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(256), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H, C, c, g.s,
+    TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(256), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H, C, c, g.s,
                        g.jmin, g.ntx, g.nty, sigmas, prm);
-    TDK_CHECK_LAUNCH("tdk_wiener(tiles)");
-    hipLaunchKernelGGL(wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s, K, g.jmin,
+    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s, K, g.jmin,
                        g.ngx, prm);
-    TDK_CHECK_LAUNCH("tdk_wiener(finish)");
   }
   return TDK_OK;
 }

@@ -18,6 +18,8 @@ c_void_p, c_int, c_int64, c_uint32, c_float, c_size_t = C.c_void_p, C.c_int, C.c
 SIGNATURES = {
   'tdk_abi_version': (c_int, []),
   'tdk_last_error': (C.c_char_p, []),
+  'tdk_profile_enable': (c_int, [c_int]),
+  'tdk_profile_report': (c_int64, [C.c_char_p, c_int64]),
   'tdk_encode12_u16': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
   'tdk_encode12_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
   'tdk_decode12_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -75,3 +77,20 @@ def check(status: int) -> None:
   """Map a tdk_status to the reference's error type (TORCH_CHECK -> RuntimeError)."""
   if status != 0:
     raise RuntimeError(lib.tdk_last_error().decode('utf-8', 'replace'))
+
+
+def profile_enable(on: bool) -> None:
+  """Switch the library's per-kernel event timer on (clearing old records) or off."""
+  check(lib.tdk_profile_enable(int(on)))
+
+
+def profile_report() -> dict:
+  """{kernel name: (launches, total device ms)} for everything launched since profile_enable(True)."""
+  need = lib.tdk_profile_report(None, 0)
+  buf = C.create_string_buffer(int(need) + 16)
+  lib.tdk_profile_report(buf, len(buf))
+  out = {}
+  for line in buf.value.decode().splitlines():
+    name, count, ms = line.rsplit(' ', 2)
+    out[name] = (int(count), float(ms))
+  return out
