@@ -1,0 +1,63 @@
+"""Run one op of the hot path a few times on synthetic 12 MP data -- the target of the
+rocprofv3 passes whose summaries are committed in this directory.
+
+  python profiles/run_op.py {rcd,wiener,bilateral,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / 'torch-darktable_amd'))
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('op')
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--storage', default='f16')
+    ap.add_argument('--width', type=int, default=4096)
+    ap.add_argument('--height', type=int, default=3072)
+    a = ap.parse_args()
+    import torch_darktable as td
+    from torch_darktable.synthetic import synthetic_bayer
+
+    dev = torch.device('cuda', 0)
+    w, h = a.width, a.height
+    dt = torch.float16 if a.storage == 'f16' else torch.float32
+    bayer = synthetic_bayer(h, w, 1234, dev).to(dt)
+    rcd = td.RCD(dev, (w, h), td.BayerPattern.RGGB)
+    rgb = rcd.process(bayer)
+    lum = td.compute_luminance(rgb)
+    loglum = td.compute_log_luminance(rgb, 1e-4)
+    wiener = td.Wiener(dev, (w, h), 4, 32)
+    bil = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
+    params = td.TonemapParameters(0.75, 2.0, 1.0, 0.0)
+    metrics = td.compute_image_metrics([rgb], 8)
+    torch.cuda.synchronize()
+    for _ in range(a.iters):
+        if a.op == 'rcd':
+            rcd.process(bayer)
+        elif a.op == 'wiener':
+            wiener.process(loglum.unsqueeze(2), 0.075)
+        elif a.op == 'bilateral':
+            bil.process(lum, 0.4)
+        elif a.op == 'tonemap':
+            td.reinhard_tonemap(rgb, metrics, params)
+        elif a.op == 'luminance':
+            td.modify_luminance(rgb, td.compute_luminance(rgb))
+        elif a.op == 'isp':
+            x = rcd.process(bayer)
+            x = wiener.process_log_luminance(x, 0.075)
+            x = bil.process_rgb(x, 0.4)
+            td.reinhard_tonemap(x, td.compute_image_metrics([x], 8), params)
+        else:
+            raise SystemExit(f'unknown op {a.op}')
+    torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    main()

@@ -9,18 +9,16 @@
 //
 // MI355X design
 //  * splat: MI355X resolves global float atomics at the memory side (~1.3 TB/s of added bytes
-//    chip-wide), so the reference's 8 atomics/px cannot stream.  Each 256-thread workgroup
-//    accumulates a 64 x 64 pixel tile into an LDS-private sub-grid (ds_add_f32) and flushes
-//    only its touched cells with one global atomic each (4-30x fewer atomic bytes).  Tiles whose
-//    footprint exceeds the LDS budget (tiny sigma_s) fall back to direct global atomics.
+//    chip-wide) and LDS float atomics cost ~150 cycles per wave instruction, so the reference's
+//    8 atomics/px scatter is turned into a gather: one thread per grid column sums the pixels
+//    that touch it (see splat_gather_kernel).  No atomics, no memset, deterministic.
 //  * blur x+y: one kernel; a 64 x 16 cell tile + 2-cell halo of one z-slice is staged in LDS,
 //    blurred along x into a second LDS buffer and along y on the way out (coalesced along x;
 //    the reference walks each line serially in one thread, uncoalesced for x).
 //  * z derivative: one thread per (x, y) column, coalesced along x, register window over z.
 //  * slice: trilinear gather from the (L2/MALL-resident) grid, fp32 or fp16 planes.
 //  The zero-extended stencil forms below are bit-identical to the reference's edge-case
-//  formulas (x + 0 == x); only the splat's float-add order differs (as it does run to run in
-//  the reference).
+//  formulas (x + 0 == x); and the gather sums in raster order, so the whole op is bit-identical to the oracle.
 #include "tdk_common.h"
 
 namespace {
@@ -67,60 +65,52 @@ __device__ __forceinline__ Sample make_sample(int x, int y, float L, GridDims d,
   return s;
 }
 
-__device__ __forceinline__ int cell_base(int p, float sigma_s, int size) {
+// ---- splat as a GATHER: one thread per grid column (cx, cy) walks the pixels whose trilinear
+// footprint touches it, in raster order, and accumulates its sz cells in a private LDS column
+// (plain read-modify-write by the owning thread).  No atomics at all -- LDS float atomics cost
+// ~150 cycles per wave instruction and global ones are capped at ~1.3 TB/s on MI355X -- and the
+// float sums come out in the same order as a sequential raster-order splat, i.e. bit-identical
+// to the oracle and identical run to run (the reference's atomic order is not).
+// A pixel contributes to column cx when its base cell is cx (weight 1 - f) or cx - 1 (weight f).
+__device__ __forceinline__ float axis_weight(int p, float sigma_s, int size, int cell) {
   const float g = clampf((float)p / sigma_s, 0.0f, (float)(size - 1));
-  return min((int)g, size - 2);
+  const int ib = min((int)g, size - 2);
+  const float f = g - (float)ib;
+  return (ib == cell) ? (1.0f - f) : ((ib == cell - 1) ? f : -1.0f);  // -1: no contribution
 }
 
-constexpr int SPT = 64;              // splat tile edge in pixels
-constexpr int SPLAT_LDS = 12288;     // floats (48 KB)
-
 template <typename T>
-__global__ __launch_bounds__(256) void splat_kernel(const T* __restrict__ lum, float* __restrict__ grid, int width, int height, GridDims d,
-                                                    float sigma_s, float sigma_r) {
-  __shared__ float local[SPLAT_LDS];
-  const int x0 = blockIdx.x * SPT, y0 = blockIdx.y * SPT;
-  const int x1 = min(x0 + SPT, width) - 1, y1 = min(y0 + SPT, height) - 1;
-  const int cx0 = cell_base(x0, sigma_s, d.sx), cy0 = cell_base(y0, sigma_s, d.sy);
-  const int ldx = cell_base(x1, sigma_s, d.sx) - cx0 + 2, ldy = cell_base(y1, sigma_s, d.sy) - cy0 + 2;
-  const int ncell = ldx * ldy * d.sz;
-  const bool use_lds = ncell <= SPLAT_LDS;  // workgroup-uniform
+__global__ __launch_bounds__(256) void splat_gather_kernel(const T* __restrict__ lum, float* __restrict__ grid, int width, int height, GridDims d,
+                                                           float sigma_s, float sigma_r) {
+  extern __shared__ float colacc[];  // [sz][256]
+  const int cx = blockIdx.x * 32 + (threadIdx.x & 31), cy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int tid = threadIdx.x;
+  for (int z = 0; z < d.sz; z++) colacc[z * 256 + tid] = 0.0f;
+  if (cx >= d.sx || cy >= d.sy) return;
   const float contrib = 1.0f / (sigma_s * sigma_s);
-  if (use_lds) {
-    for (int i = threadIdx.x; i < ncell; i += 256) local[i] = 0.0f;
-    __syncthreads();
-  }
-  const int tw = x1 - x0 + 1, th = y1 - y0 + 1;
-  for (int i = threadIdx.x; i < tw * th; i += 256) {
-    const int ly = i / tw, lx = i - ly * tw;
-    const int x = x0 + lx, y = y0 + ly;
-    const Sample s = make_sample(x, y, ld(lum, (size_t)y * width + x), d, sigma_s, sigma_r);
-    const float ax = 1.0f - s.fx, ay = 1.0f - s.fy, az = 1.0f - s.fz, bx = s.fx, by = s.fy, bz = s.fz;
-    const float w000 = ax * ay * az * contrib, w100 = bx * ay * az * contrib, w010 = ax * by * az * contrib, w110 = bx * by * az * contrib;
-    const float w001 = ax * ay * bz * contrib, w101 = bx * ay * bz * contrib, w011 = ax * by * bz * contrib, w111 = bx * by * bz * contrib;
-    if (use_lds) {
-      float* g = local + (s.ix - cx0) + ldx * ((s.iy - cy0) + ldy * s.iz);
-      const int oy = ldx, oz = ldx * ldy;
-      atomicAdd(g, w000); atomicAdd(g + 1, w100); atomicAdd(g + oy, w010); atomicAdd(g + oy + 1, w110);
-      atomicAdd(g + oz, w001); atomicAdd(g + oz + 1, w101); atomicAdd(g + oz + oy, w011); atomicAdd(g + oz + oy + 1, w111);
-    } else {
-      float* g = grid + s.ix + (size_t)d.sx * (s.iy + (size_t)d.sy * s.iz);
-      const size_t oy = d.sx, oz = (size_t)d.sx * d.sy;
-      atomicAdd(g, w000); atomicAdd(g + 1, w100); atomicAdd(g + oy, w010); atomicAdd(g + oy + 1, w110);
-      atomicAdd(g + oz, w001); atomicAdd(g + oz + 1, w101); atomicAdd(g + oz + oy, w011); atomicAdd(g + oz + oy + 1, w111);
+  // candidate pixel window; the last column also collects every pixel clamped onto it
+  const int x_lo = max(0, (int)floorf(sigma_s * (float)(cx - 1)) - 1);
+  const int x_hi = (cx == d.sx - 1) ? width - 1 : min(width - 1, (int)ceilf(sigma_s * (float)(cx + 1)) + 1);
+  const int y_lo = max(0, (int)floorf(sigma_s * (float)(cy - 1)) - 1);
+  const int y_hi = (cy == d.sy - 1) ? height - 1 : min(height - 1, (int)ceilf(sigma_s * (float)(cy + 1)) + 1);
+  for (int y = y_lo; y <= y_hi; y++) {
+    const float wy = axis_weight(y, sigma_s, d.sy, cy);
+    if (wy < 0.0f) continue;
+    for (int x = x_lo; x <= x_hi; x++) {
+      const float wx = axis_weight(x, sigma_s, d.sx, cx);
+      if (wx < 0.0f) continue;
+      const float L = ld(lum, (size_t)y * width + x);
+      const float gz = clampf(L / sigma_r, 0.0f, (float)(d.sz - 1));
+      const int iz = min((int)gz, d.sz - 2);
+      const float fz = gz - (float)iz;
+      const float wxy = wx * wy;
+      colacc[iz * 256 + tid] += wxy * (1.0f - fz) * contrib;
+      colacc[(iz + 1) * 256 + tid] += wxy * fz * contrib;
     }
   }
-  if (use_lds) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncell; i += 256) {
-      const float v = local[i];
-      if (v != 0.0f) {
-        const int lz = i / (ldx * ldy), rem = i - lz * ldx * ldy;
-        const int lyc = rem / ldx, lxc = rem - lyc * ldx;
-        atomicAdd(grid + (cx0 + lxc) + (size_t)d.sx * ((cy0 + lyc) + (size_t)d.sy * lz), v);
-      }
-    }
-  }
+  const size_t plane = (size_t)d.sx * d.sy;
+  float* g = grid + (size_t)cy * d.sx + cx;
+  for (int z = 0; z < d.sz; z++) g[z * plane] = colacc[z * 256 + tid];
 }
 
 // ---- blur along x then y for one z-slice tile
@@ -199,8 +189,11 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
   float* tmp = grid + tdk_align_up(ncell, 64);
   const T* in = reinterpret_cast<const T*>(lum_in);
   T* out = reinterpret_cast<T*>(lum_out);
-  TDK_HIP_CALL(hipMemsetAsync(grid, 0, ncell * sizeof(float), s), "tdk_bilateral(memset)");
-  TDK_LAUNCH("tdk_bilateral(splat)", splat_kernel<T>, dim3(tdk_div_up(width, SPT), tdk_div_up(height, SPT)), dim3(256), 0, s, in, grid, width, height, d, sigma_s, sigma_r);
+  const size_t splat_lds = (size_t)d.sz * 256 * sizeof(float);
+  TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
+               "tdk_bilateral(hipFuncSetAttribute)");
+  TDK_LAUNCH("tdk_bilateral(splat)", splat_gather_kernel<T>, dim3(tdk_div_up(d.sx, 32), tdk_div_up(d.sy, 8)), dim3(256), splat_lds, s, in, grid, width, height,
+             d, sigma_s, sigma_r);
   TDK_LAUNCH("tdk_bilateral(blur_xy)", blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);
   TDK_LAUNCH("tdk_bilateral(blur_z)", blur_z_kernel, dim3((unsigned)tdk_div_up64((int64_t)d.sx * d.sy, 256)), dim3(256), 0, s, tmp, grid, d);
   const int64_t npix = (int64_t)width * height;

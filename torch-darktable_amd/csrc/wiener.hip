@@ -14,10 +14,11 @@
 //  * a wave processes 64/K tiles at once, one tile ROW per lane: the K-point FFTs run entirely
 //    in registers (fully unrolled radix-2 DIT, immediate twiddles, no cross-lane traffic); the
 //    two transposes per direction go through a per-wave padded LDS tile;
-//  * a 256-thread workgroup owns a GT x GT group of tile origins (64 x 64 output pixels) and
-//    overlap-adds its tiles into an LDS accumulator with ds_add_f32 -- no global atomics at all;
-//  * each workgroup writes its (64 - s + K)^2 partial slab once; a second streaming kernel sums
-//    the <= 4 slabs that overlap an output pixel in a fixed order and applies the mask.  The
+//  * a 512-thread workgroup owns 8 tile rows x (64/K * ov) tile columns (64 x 8s output pixels);
+//    each wave overlap-adds its tile row into a private LDS accumulator with plain 16-B
+//    read-modify-writes -- no atomics anywhere (LDS float atomics are ~150 cycles each);
+//  * each workgroup writes its (64 - s + K) x (7s + K) partial slab once; a second streaming
+//    kernel sums the <= 4 slabs that overlap an output pixel in a fixed order and applies the mask.  The
 //    mask is input-independent and separable (every pixel is covered by exactly ov x ov tiles):
 //    mask(x, y) = m1[x mod s] * m1[y mod s], m1[r] = sum_k wf[r + k s] * wi[r + k s], so it is
 //    never accumulated.
@@ -149,42 +150,58 @@ __device__ __forceinline__ void load_row(const T* __restrict__ row_ptr, int ox, 
   }
 }
 
-// One workgroup: GT x GT tile origins of one channel -> one slab of RS x RS partial sums.
+constexpr int NW = 8;  // waves per workgroup == tile rows per group
+
+// LDS row stride of a per-wave accumulator: >= n, a multiple of 4 floats with (stride / 4) odd,
+// so the 16-B accesses of 16 lanes on consecutive rows fall in 16 different 4-bank slots.
+__host__ __device__ inline int acc_stride(int n) {
+  int st = (n + 3) & ~3;
+  if (((st >> 2) & 1) == 0) st += 4;
+  return st;
+}
+
+// One workgroup (8 waves) = one group of 8 tile rows x (TPW * ov) tile columns of one channel,
+// i.e. a 64 (x) by 8 s (y) block of output pixels.  Wave w owns tile row w and overlap-adds its
+// tiles into a PRIVATE K-row LDS accumulator with plain 16-B read-modify-writes: the tiles a
+// wave handles at the same time are ov columns apart (they do not overlap) and consecutive tiles
+// are sequential, so no atomics are needed (ds_add_f32 measured ~150 cycles per wave
+// instruction on gfx950 -- it dominated the first version of this kernel).  The eight private
+// accumulators are folded in a fixed order when the group's slab is written: the whole op is
+// deterministic, unlike the reference's atomic overlap-add.
 template <typename T, int K>
-__global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan, int s,
-                                                    int jmin, int ntile_x, int ntile_y, const float* __restrict__ sigmas, WParams prm) {
-  constexpr int TPW = 64 / K;          // tiles per wave
-  constexpr int TPB = 4 * TPW;         // tiles in flight per workgroup
-  extern __shared__ float lds[];
-  const int GT = BS / s;
-  const int RS = BS - s + K;           // slab edge
-  const int RSP = RS | 1;              // odd LDS row stride: the per-lane rows of a tile hit distinct banks
-  float* acc = lds;                    // RS rows of RSP
-  float* tbuf = lds + RS * RSP + (threadIdx.x >> 6) * (TPW * K * (K + 1));  // per-wave transpose scratch
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan,
+                                                        int s, int ov, int jmin, int ntile_x, int ntile_y, const float* __restrict__ sigmas,
+                                                        WParams prm) {
+  constexpr int TPW = 64 / K;  // tiles per wave
+  extern __shared__ __align__(16) float lds[];
+  const int GTX = TPW * ov;
+  const int RSX = BS - s + K, RSY = (NW - 1) * s + K;
+  const int AST = acc_stride(RSX);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per_wave = K * AST + TPW * K * (K + 1);
+  float* acc = lds + wave * per_wave;  // K rows of AST
+  float* tbuf = acc + K * AST;         // per-wave transpose scratch
   const int row = lane & (K - 1), slot = lane / K;
   float* my_t = tbuf + slot * (K * (K + 1));
 
-  for (int i = threadIdx.x; i < RS * RSP; i += 256) acc[i] = 0.0f;
-  __syncthreads();
+  for (int i = lane; i < K * AST; i += 64) acc[i] = 0.0f;
 
   const float sigma = sigmas[chan];
   const float sig2 = sigma * sigma;
-  const int jx0 = jmin + blockIdx.x * GT, jy0 = jmin + blockIdx.y * GT;  // first tile origin index of the group
-  const int rx0 = jx0 * s, ry0 = jy0 * s;                               // slab origin in image coordinates
-  const int ngroup = GT * GT;
-  const int wave = threadIdx.x >> 6;
+  const int jx0 = jmin + blockIdx.x * GTX, jy0 = jmin + blockIdx.y * NW;  // first tile origin index of the group
+  const int jy = jy0 + wave;
+  const int oy = jy * s;
+  const bool row_active = jy < jmin + ntile_y;
+  const int sy = reflect_index(oy + row, H);
 
-  for (int base = 0; base < ngroup; base += TPB) {
-    const int t = base + wave * TPW + slot;          // tile index inside the group
-    const int ty_i = t / GT, tx_i = t - ty_i * GT;
-    const bool active = (t < ngroup) && (jx0 + tx_i < jmin + ntile_x) && (jy0 + ty_i < jmin + ntile_y);
-    const int ox = (jx0 + tx_i) * s, oy = (jy0 + ty_i) * s;
+  for (int base = 0; base < ov; base++) {
+    const int tx_i = base + slot * ov;  // the wave's concurrent tiles are ov columns apart: disjoint footprints
+    const bool active = row_active && (jx0 + tx_i < jmin + ntile_x);
+    const int ox = (jx0 + tx_i) * s;
 
     float re[K], im[K];
     float mean = 0.0f;
     if (active) {
-      const int sy = reflect_index(oy + row, H);
       load_row<T, K>(img + (size_t)sy * W * C, ox, W, C, chan, re);
       float sum = 0.0f;
 #pragma unroll
@@ -217,19 +234,36 @@ __global__ __launch_bounds__(256) void wiener_tiles(const T* __restrict__ img, f
 
     if (active) {
       const float wy = prm.wf[row], iy = prm.wi[row];
-      float* dst = acc + (oy - ry0 + row) * RSP + (ox - rx0);
+      float* dst = acc + row * AST + tx_i * s;
+      if ((s & 3) == 0) {
 #pragma unroll
-      for (int k = 0; k < K; k++) {
-        const float fw = prm.wf[k] * wy, iw = prm.wi[k] * iy;
-        atomicAdd(dst + k, (re[k] + mean * fw) * iw);
+        for (int k = 0; k < K; k += 4) {
+          float4 a = *reinterpret_cast<float4*>(dst + k);
+          a.x += (re[k] + mean * (prm.wf[k] * wy)) * (prm.wi[k] * iy);
+          a.y += (re[k + 1] + mean * (prm.wf[k + 1] * wy)) * (prm.wi[k + 1] * iy);
+          a.z += (re[k + 2] + mean * (prm.wf[k + 2] * wy)) * (prm.wi[k + 2] * iy);
+          a.w += (re[k + 3] + mean * (prm.wf[k + 3] * wy)) * (prm.wi[k + 3] * iy);
+          *reinterpret_cast<float4*>(dst + k) = a;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; k++) dst[k] += (re[k] + mean * (prm.wf[k] * wy)) * (prm.wi[k] * iy);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  float* slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(RS * RS);
-  for (int i = threadIdx.x; i < RS * RS; i += 256) {
-    const int r = i / RS, c = i - r * RS;
-    slab[i] = acc[r * RSP + c];
+  // fold the private accumulators: slab row r gets wave w's row r - w*s, for 0 <= r - w*s < K
+  float* slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(RSX * RSY);
+  for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
+    const int r = i / RSX, c = i - r * RSX;
+    float v = 0.0f;
+    for (int w = 0; w < NW; w++) {
+      const int rr = r - w * s;
+      if (rr >= 0 && rr < K) v += lds[w * per_wave + rr * AST + c];
+    }
+    slab[i] = v;
   }
 }
 
@@ -238,19 +272,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int C, int chan, int s,
                                                      int K, int jmin, int ngx, WParams prm) {
   const int64_t n = (int64_t)W * H;
-  const int RS = BS - s + K;
+  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
   const int u0 = -jmin * s;  // = (ov - 1) * s: pixel 0 sits at this offset inside group 0
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
     const int ux = x + u0, uy = y + u0;
-    const int gx = ux / BS, gy = uy / BS;
-    const int offx = ux - gx * BS, offy = uy - gy * BS;
+    const int gx = ux / BS, gy = uy / BSY;
+    const int offx = ux - gx * BS, offy = uy - gy * BSY;
     const bool px = (offx < K - s) && gx > 0, py = (offy < K - s) && gy > 0;
-    auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RS * RS) + (size_t)oy * RS + ox]; };
+    auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RSX * RSY) + (size_t)oy * RSX + ox]; };
     float v = slab_at(gx, gy, offx, offy);
     if (px) v += slab_at(gx - 1, gy, offx + BS, offy);
-    if (py) v += slab_at(gx, gy - 1, offx, offy + BS);
-    if (px && py) v += slab_at(gx - 1, gy - 1, offx + BS, offy + BS);
+    if (py) v += slab_at(gx, gy - 1, offx, offy + BSY);
+    if (px && py) v += slab_at(gx - 1, gy - 1, offx + BS, offy + BSY);
     const float mask = prm.m1[x % s] * prm.m1[y % s];
     st(out, (size_t)i * C + chan, v / (mask + 1e-15f));
   }
@@ -269,7 +303,7 @@ void make_window(int K, double weight, float* w) {
 }
 
 struct Geometry {
-  int s, jmin, ntx, nty, ngx, ngy, RS;
+  int s, jmin, ntx, nty, ngx, ngy, RSX, RSY;
 };
 
 Geometry geometry(int W, int H, int K, int ov) {
@@ -278,10 +312,11 @@ Geometry geometry(int W, int H, int K, int ov) {
   g.jmin = -(ov - 1);                                  // first origin index whose tile covers pixel 0
   g.ntx = (W - 1) / g.s - g.jmin + 1;                  // origins jmin .. floor((W-1)/s)
   g.nty = (H - 1) / g.s - g.jmin + 1;
-  const int GT = BS / g.s;
-  g.ngx = tdk_div_up(g.ntx, GT);
-  g.ngy = tdk_div_up(g.nty, GT);
-  g.RS = BS - g.s + K;
+  const int GTX = (64 / K) * ov;                       // == BS / s
+  g.ngx = tdk_div_up(g.ntx, GTX);
+  g.ngy = tdk_div_up(g.nty, NW);
+  g.RSX = BS - g.s + K;
+  g.RSY = (NW - 1) * g.s + K;
   return g;
 }
 
@@ -298,17 +333,17 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   }
   float* slabs = reinterpret_cast<float*>(workspace);
   constexpr int TPW = 64 / K;
-  const size_t lds_bytes = ((size_t)g.RS * (g.RS | 1) + 4 * TPW * K * (K + 1)) * sizeof(float);
+  const size_t lds_bytes = (size_t)NW * ((size_t)K * acc_stride(g.RSX) + TPW * K * (K + 1)) * sizeof(float);
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_wiener(hipFuncSetAttribute)");
   const int64_t npix = (int64_t)W * H;
   int64_t fin_blocks = tdk_div_up64(npix, 256);
   if (fin_blocks > 4096) fin_blocks = 4096;
   for (int c = 0; c < C; c++) {
-    TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(256), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H, C, c, g.s,
-                       g.jmin, g.ntx, g.nty, sigmas, prm);
-    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s, K, g.jmin,
-                       g.ngx, prm);
+    TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(64 * NW), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H,
+               C, c, g.s, ov, g.jmin, g.ntx, g.nty, sigmas, prm);
+    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
+               K, g.jmin, g.ngx, prm);
   }
   return TDK_OK;
 }
@@ -319,7 +354,7 @@ TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
   (void)channels;  // channels are processed one after another through the same slabs
   const Geometry g = geometry(width, height, tile_size, overlap_factor);
-  return tdk_align_up((size_t)g.ngx * g.ngy * g.RS * g.RS * sizeof(float), 256);
+  return tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY * sizeof(float), 256);
 }
 
 TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
