@@ -40,6 +40,7 @@ struct WParams {
   float wf[32];  // analysis (FFT) window
   float wi[32];  // synthesis (interpolation) window
   float m1[16];  // separable mask factor, index p mod s
+  float wfwi[32];  // wf[k] * wi[k]
 };
 
 // cos/sin(2 pi k / 32), k = 0..15
@@ -150,6 +151,29 @@ __device__ __forceinline__ void load_row(const T* __restrict__ row_ptr, int ox, 
   }
 }
 
+// dst[k] += (v[k] + mean * wf[k] wf[ty]) * (wi[k] wi[ty])  (reference denoise.cu:172-175), written as
+// (v[k] * wi[ty]) * wi[k] + (mean * wf[ty] wi[ty]) * (wf[k] wi[k]) so that every per-column factor is
+// a scalar (SGPR) operand instead of 64 per-lane registers.  16-B read-modify-writes when the
+// column offset allows.
+template <int K>
+__device__ __forceinline__ void accumulate_row(float* dst, const float (&v)[K], float mean, float wy, float iy, const WParams& prm, bool vec) {
+  const float mw = mean * (wy * iy);
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+      float4 a = *reinterpret_cast<float4*>(dst + k);
+      a.x += (v[k] * iy) * prm.wi[k] + mw * prm.wfwi[k];
+      a.y += (v[k + 1] * iy) * prm.wi[k + 1] + mw * prm.wfwi[k + 1];
+      a.z += (v[k + 2] * iy) * prm.wi[k + 2] + mw * prm.wfwi[k + 2];
+      a.w += (v[k + 3] * iy) * prm.wi[k + 3] + mw * prm.wfwi[k + 3];
+      *reinterpret_cast<float4*>(dst + k) = a;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k++) dst[k] += (v[k] * iy) * prm.wi[k] + mw * prm.wfwi[k];
+  }
+}
+
 constexpr int NW = 8;  // waves per workgroup == tile rows per group
 
 // LDS row stride of a per-wave accumulator: >= n, a multiple of 4 floats with (stride / 4) odd,
@@ -193,63 +217,90 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   const int oy = jy * s;
   const bool row_active = jy < jmin + ntile_y;
   const int sy = reflect_index(oy + row, H);
+  const T* src_row = img + (size_t)sy * W * C;
+  const int partner = (lane & ~(K - 1)) | ((K - row) & (K - 1));  // lane holding column -kx of the same slot
 
-  for (int base = 0; base < ov; base++) {
-    const int tx_i = base + slot * ov;  // the wave's concurrent tiles are ov columns apart: disjoint footprints
-    const bool active = row_active && (jx0 + tx_i < jmin + ntile_x);
-    const int ox = (jx0 + tx_i) * s;
+  // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
+  // the spectra are separated with the Hermitian identities A[k] = (Z[k] + conj(Z[-k])) / 2,
+  // B[k] = (Z[k] - conj(Z[-k])) / 2i (Z[-k] sits in lane -kx, register -ky), each gets its own
+  // Wiener gain, and Z' = A' + i B' goes back through one inverse transform: re = a', im = b'.
+  // Tile a / b of slot i in step `base`: columns i*ov + 2*base (+1).  The a (b) tiles of
+  // different slots are ov columns apart, and a and b are accumulated one after the other, so
+  // the plain read-modify-writes below never collide.
+  for (int base = 0; base < (ov >> 1); base++) {
+    const int txa = slot * ov + 2 * base, txb = txa + 1;
+    const bool act_a = row_active && (jx0 + txa < jmin + ntile_x);
+    const bool act_b = row_active && (jx0 + txb < jmin + ntile_x);
+    const int oxa = (jx0 + txa) * s, oxb = (jx0 + txb) * s;
 
     float re[K], im[K];
-    float mean = 0.0f;
-    if (active) {
-      load_row<T, K>(img + (size_t)sy * W * C, ox, W, C, chan, re);
-      float sum = 0.0f;
-#pragma unroll
-      for (int k = 0; k < K; k++) sum += re[k];
-#pragma unroll
-      for (int o = K / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      mean = sum / (float)(K * K);
-      const float wy = prm.wf[row];
-#pragma unroll
-      for (int k = 0; k < K; k++) { re[k] = (re[k] - mean) * (prm.wf[k] * wy); im[k] = 0.0f; }
+    float mean_a = 0.0f, mean_b = 0.0f;
+    const float wy = prm.wf[row];
+    if (act_a) {
+      load_row<T, K>(src_row, oxa, W, C, chan, re);
     } else {
 #pragma unroll
-      for (int k = 0; k < K; k++) { re[k] = 0.0f; im[k] = 0.0f; }
+      for (int k = 0; k < K; k++) re[k] = 0.0f;
+    }
+    if (act_b) {
+      load_row<T, K>(src_row, oxb, W, C, chan, im);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) im[k] = 0.0f;
+    }
+    {
+      float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; k++) { sa += re[k]; sb += im[k]; }
+#pragma unroll
+      for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+      mean_a = sa / (float)(K * K);
+      mean_b = sb / (float)(K * K);
+#pragma unroll
+      for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
+        re[k] = ((re[k] - mean_a) * wy) * prm.wf[k];
+        im[k] = ((im[k] - mean_b) * wy) * prm.wf[k];
+      }
     }
 
     fft_inreg<K, false>(re, im);            // along x
     transpose_tile<K>(re, my_t, row);
     transpose_tile<K>(im, my_t, row);
     fft_inreg<K, false>(re, im);            // along y (lane = kx)
+
+    // separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  Index k and
+    // its mirror K-k are handled together so the partner lane still sees the untouched values.
+    auto shrink = [&](float zr, float zi, float pr, float pi, float& outr, float& outi) {
+      const float ar = 0.5f * (zr + pr), ai = 0.5f * (zi - pi);
+      const float br = 0.5f * (zi + pi), bi = -0.5f * (zr - pr);
+      const float pa = (ar * ar + ai * ai) + 1e-15f, pb = (br * br + bi * bi) + 1e-15f;
+      const float ga = fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa);
+      const float gb = fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb);
+      outr = ga * ar - gb * bi;
+      outi = ga * ai + gb * br;
+    };
 #pragma unroll
-    for (int k = 0; k < K; k++) {           // denoise.cu:181-185
-      const float power = (re[k] * re[k] + im[k] * im[k]) + 1e-15f;
-      const float gain = fmaxf(power - sig2, 0.0f) / power;
-      re[k] *= gain; im[k] *= gain;
+    for (int k = 0; k <= K / 2; k++) {
+      const int k2 = (K - k) & (K - 1);
+      const float p_k2_r = __shfl(re[k2], partner, 64), p_k2_i = __shfl(im[k2], partner, 64);  // Z[-k] for index k
+      const float p_k_r = __shfl(re[k], partner, 64), p_k_i = __shfl(im[k], partner, 64);      // Z[-k2] for index k2
+      float r0, i0, r1, i1;
+      shrink(re[k], im[k], p_k2_r, p_k2_i, r0, i0);
+      shrink(re[k2], im[k2], p_k_r, p_k_i, r1, i1);
+      re[k] = r0; im[k] = i0;
+      if (k2 != k) { re[k2] = r1; im[k2] = i1; }
     }
+
     fft_inreg<K, true>(re, im);             // inverse along y
     transpose_tile<K>(re, my_t, row);
     transpose_tile<K>(im, my_t, row);
-    fft_inreg<K, true>(re, im);             // inverse along x (lane = y again)
+    fft_inreg<K, true>(re, im);             // inverse along x (lane = y again): re = tile a, im = tile b
 
-    if (active) {
-      const float wy = prm.wf[row], iy = prm.wi[row];
-      float* dst = acc + row * AST + tx_i * s;
-      if ((s & 3) == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k += 4) {
-          float4 a = *reinterpret_cast<float4*>(dst + k);
-          a.x += (re[k] + mean * (prm.wf[k] * wy)) * (prm.wi[k] * iy);
-          a.y += (re[k + 1] + mean * (prm.wf[k + 1] * wy)) * (prm.wi[k + 1] * iy);
-          a.z += (re[k + 2] + mean * (prm.wf[k + 2] * wy)) * (prm.wi[k + 2] * iy);
-          a.w += (re[k + 3] + mean * (prm.wf[k + 3] * wy)) * (prm.wi[k + 3] * iy);
-          *reinterpret_cast<float4*>(dst + k) = a;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < K; k++) dst[k] += (re[k] + mean * (prm.wf[k] * wy)) * (prm.wi[k] * iy);
-      }
-    }
+    const float iy = prm.wi[row];
+    if (act_a) accumulate_row<K>(acc + row * AST + txa * s, re, mean_a, wy, iy, prm, (s & 3) == 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (act_b) accumulate_row<K>(acc + row * AST + txb * s, im, mean_b, wy, iy, prm, (s & 3) == 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -326,6 +377,7 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
+  for (int k = 0; k < K; k++) prm.wfwi[k] = prm.wf[k] * prm.wi[k];
   for (int r = 0; r < g.s; r++) {
     float m = 0.0f;
     for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
