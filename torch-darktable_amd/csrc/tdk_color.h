@@ -19,6 +19,8 @@ __device__ __forceinline__ float tdk_pow(float x, float y) { return powf(x, y); 
 __device__ __forceinline__ float tdk_exp(float x) { return expf(x); }
 __device__ __forceinline__ float tdk_log(float x) { return logf(x); }
 __device__ __forceinline__ float tdk_cbrt(float x) { return cbrtf(x); }
+__device__ __forceinline__ float tdk_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float tdk_sqrt(float x) { return sqrtf(x); }
 #else
 // x > 0: exp2(y * log2 x); x == 0: log2 -> -inf -> 0 for y > 0; x < 0 -> NaN (as powf for
 // non-integer y).  pow(x, 0) == 1 including x == 0 is kept by the y == 0 test.
@@ -29,6 +31,10 @@ __device__ __forceinline__ float tdk_pow(float x, float y) {
 __device__ __forceinline__ float tdk_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float tdk_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 __device__ __forceinline__ float tdk_cbrt(float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 3.0f)); }
+// a / b as a * rcp(b) (v_rcp_f32, 1 ulp) -- the reference's fast-math division class; the IEEE
+// sequence is ~10 instructions and the colour kernels carry ~18 divisions per pixel.
+__device__ __forceinline__ float tdk_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float tdk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #endif
 
 __device__ __forceinline__ f3 clip3(f3 a) { return mk3(clip01(a.x), clip01(a.y), clip01(a.z)); }
@@ -51,12 +57,15 @@ __device__ __forceinline__ f3 xyz_to_rgb_lin(f3 v) {
 #define TDK_D65_Y 1.0f
 #define TDK_D65_Z 1.08883f
 
+#ifdef TDK_PRECISE_MATH
+#error "TDK_PRECISE_MATH: restore the literal divisions in namespaces cA / cB before enabling"
+#endif
 namespace cA {  // device_conversions.h
 
 __device__ __forceinline__ float srgb_to_linear(float c) {
   const float a = 0.055f;
   const float lin = c * (1.0f / 12.92f);
-  return (c > 0.04045f) ? tdk_pow((c + a) / (1.0f + a), 2.4f) : lin;
+  return (c > 0.04045f) ? tdk_pow((c + a) * (1.0f / (1.0f + a)), 2.4f) : lin;
 }
 __device__ __forceinline__ float linear_to_srgb(float c) {
   const float a = 0.055f;
@@ -65,11 +74,11 @@ __device__ __forceinline__ float linear_to_srgb(float c) {
 __device__ __forceinline__ float lab_f(float t) { return (t > 0.008856f) ? tdk_pow(t, 1.0f / 3.0f) : (t * 7.787f + 16.0f / 116.0f); }
 __device__ __forceinline__ float lab_f_inv(float t) {
   const float t3 = t * t * t;
-  return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) / 7.787f;
+  return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) * (1.0f / 7.787f);
 }
 __device__ __forceinline__ f3 rgb_to_xyz(f3 c) { return rgb_to_xyz_lin(mk3(srgb_to_linear(c.x), srgb_to_linear(c.y), srgb_to_linear(c.z))); }
 __device__ __forceinline__ f3 xyz_to_lab(f3 xyz) {
-  const float fx = lab_f(xyz.x / TDK_D65_X), fy = lab_f(xyz.y / TDK_D65_Y), fz = lab_f(xyz.z / TDK_D65_Z);
+  const float fx = lab_f(xyz.x * (1.0f / TDK_D65_X)), fy = lab_f(xyz.y), fz = lab_f(xyz.z * (1.0f / TDK_D65_Z));
   return mk3((116.0f / 100.0f) * fy - (16.0f / 100.0f), (500.0f / 128.0f) * (fx - fy), (200.0f / 128.0f) * (fy - fz));
 }
 __device__ __forceinline__ f3 lab_to_xyz(f3 lab) {
@@ -107,11 +116,11 @@ __device__ __forceinline__ f3 rgb_to_hsl(f3 c) {
   float h = 0.0f, s = 0.0f;
   const float l = (mx + mn) * 0.5f;
   if (delta > 1e-6f) {
-    s = (l < 0.5f) ? delta / (mx + mn) : delta / (2.0f - mx - mn);
-    if (mx == c.x) h = (c.y - c.z) / delta + (c.y < c.z ? 6.0f : 0.0f);
-    else if (mx == c.y) h = (c.z - c.x) / delta + 2.0f;
-    else h = (c.x - c.y) / delta + 4.0f;
-    h /= 6.0f;
+    s = (l < 0.5f) ? tdk_div(delta, mx + mn) : tdk_div(delta, 2.0f - mx - mn);
+    if (mx == c.x) h = tdk_div(c.y - c.z, delta) + (c.y < c.z ? 6.0f : 0.0f);
+    else if (mx == c.y) h = tdk_div(c.z - c.x, delta) + 2.0f;
+    else h = tdk_div(c.x - c.y, delta) + 4.0f;
+    h *= (1.0f / 6.0f);
   }
   return mk3(h, s, l);
 }
@@ -135,13 +144,13 @@ __device__ __forceinline__ f3 modify_hsl(f3 rgb, float hue, float sat, float lum
   float nh = hsl.x + hue;
   if (nh < 0.0f) nh += 1.0f;
   if (nh > 1.0f) nh -= 1.0f;
-  const float ns = tdk_pow(hsl.y, 1.0f / (1.0f + sat));
-  const float nl = tdk_pow(hsl.z, 1.0f / (1.0f + lum));
+  const float ns = tdk_pow(hsl.y, tdk_div(1.0f, 1.0f + sat));
+  const float nl = tdk_pow(hsl.z, tdk_div(1.0f, 1.0f + lum));
   return clip3(hsl_to_rgb(mk3(nh, ns, nl)));
 }
 __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
   const f3 lab = rgb_to_lab(rgb);
-  const float chroma = sqrtf(lab.y * lab.y + lab.z * lab.z);
+  const float chroma = tdk_sqrt(lab.y * lab.y + lab.z * lab.z);
   const float ls = 1.0f - amount * chroma * 0.25f;
   const float ss = 1.0f + amount * chroma;
   return clip3(lab_to_rgb(mk3(lab.x * ls, lab.y * ss, lab.z * ss)));
@@ -152,7 +161,7 @@ __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
 namespace cB {  // device_color_conversions.h
 
 __device__ __forceinline__ float linear_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * tdk_pow(c, 1.0f / 2.4f) - 0.055f; }
-__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : tdk_pow((c + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c * (1.0f / 12.92f) : tdk_pow((c + 0.055f) * (1.0f / 1.055f), 2.4f); }
 __device__ __forceinline__ float lab_f(float t) {
   const float delta = 6.0f / 29.0f;
   const float delta_cubed = delta * delta * delta;
@@ -168,21 +177,21 @@ __device__ __forceinline__ float lab_f_inv(float t) {
 }
 __device__ __forceinline__ f3 rgb_to_lab(f3 c) {
   const f3 xyz = rgb_to_xyz_lin(mk3(srgb_to_linear(c.x), srgb_to_linear(c.y), srgb_to_linear(c.z)));
-  const float fx = lab_f(xyz.x / TDK_D65_X), fy = lab_f(xyz.y / TDK_D65_Y), fz = lab_f(xyz.z / TDK_D65_Z);
+  const float fx = lab_f(xyz.x * (1.0f / TDK_D65_X)), fy = lab_f(xyz.y), fz = lab_f(xyz.z * (1.0f / TDK_D65_Z));
   const float L = 116.0f * fy - 16.0f, a = 500.0f * (fx - fy), b = 200.0f * (fy - fz);
-  return mk3(L / 100.0f, a / 128.0f, b / 128.0f);
+  return mk3(L * (1.0f / 100.0f), a * (1.0f / 128.0f), b * (1.0f / 128.0f));
 }
 __device__ __forceinline__ f3 lab_to_rgb(f3 lab) {
   const float L = lab.x * 100.0f, a = lab.y * 128.0f, b = lab.z * 128.0f;
-  const float fy = (L + 16.0f) / 116.0f;
-  const float fx = a / 500.0f + fy;
-  const float fz = fy - b / 200.0f;
+  const float fy = (L + 16.0f) * (1.0f / 116.0f);
+  const float fx = a * (1.0f / 500.0f) + fy;
+  const float fz = fy - b * (1.0f / 200.0f);
   const f3 lin = xyz_to_rgb_lin(mk3(lab_f_inv(fx) * TDK_D65_X, lab_f_inv(fy) * TDK_D65_Y, lab_f_inv(fz) * TDK_D65_Z));
   return mk3(linear_to_srgb(lin.x), linear_to_srgb(lin.y), linear_to_srgb(lin.z));
 }
 __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
   const f3 lab = rgb_to_lab(rgb);
-  const float chroma = sqrtf(lab.y * lab.y + lab.z * lab.z);
+  const float chroma = tdk_sqrt(lab.y * lab.y + lab.z * lab.z);
   const float ls = 1.0f - amount * chroma * 0.25f;
   const float ss = 1.0f + amount * chroma;
   return clip3(lab_to_rgb(mk3(lab.x * ls, lab.y * ss, lab.z * ss)));

@@ -119,14 +119,14 @@ __global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __re
 // ------------------------------------------------------------------ tonemaps
 // color_adaption.h:17-29
 __device__ __forceinline__ float map_key_of(float log_mean) {
-  const float normalized = fmaxf(0.0f, fminf(1.0f, (-log_mean) / 9.21034f));
+  const float normalized = fmaxf(0.0f, fminf(1.0f, (-log_mean) * (1.0f / 9.21034f)));
   return 0.3f + 0.7f * tdk_pow(normalized, 1.4f);
 }
 // aces.cu:13-34
 __device__ __forceinline__ float rrt_odt(float v) {
   const float a = v * (v + 0.0245786f) - 0.000090537f;
   const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
-  return a / b;
+  return tdk_div(a, b);
 }
 __device__ __forceinline__ f3 aces_fit(f3 c) {
   const f3 a = mk3(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z,
@@ -139,7 +139,7 @@ __device__ __forceinline__ f3 aces_fit(f3 c) {
 __device__ __forceinline__ uint32_t to_u8(float x) { return (uint32_t)fminf(roundf(x * 255.0f), 255.0f); }
 
 struct TmConst {
-  float key, exposure, m0, m1, m2, inv_gamma, vibrance, light_adapt, aces_scale;
+  float key, inv_exposure, m0, m1, m2, inv_gamma, vibrance, light_adapt, aces_scale;
 };
 
 template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst& k) {
@@ -148,10 +148,10 @@ template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst
     tm = aces_fit(mk3(c.x * k.aces_scale, c.y * k.aces_scale, c.z * k.aces_scale));
   } else {
     const f3 mean = mk3(lerpf(k.light_adapt, k.m0, c.x), lerpf(k.light_adapt, k.m1, c.y), lerpf(k.light_adapt, k.m2, c.z));
-    const f3 ad = mk3(tdk_pow(mean.x / k.exposure, k.key), tdk_pow(mean.y / k.exposure, k.key), tdk_pow(mean.z / k.exposure, k.key));
-    if constexpr (MODE == TDK_TONEMAP_REINHARD) tm = mk3(c.x / (ad.x + c.x), c.y / (ad.y + c.y), c.z / (ad.z + c.z));
-    else if constexpr (MODE == TDK_TONEMAP_LINEAR) tm = mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z);
-    else tm = aces_fit(mk3(c.x / ad.x, c.y / ad.y, c.z / ad.z));
+    const f3 ad = mk3(tdk_pow(mean.x * k.inv_exposure, k.key), tdk_pow(mean.y * k.inv_exposure, k.key), tdk_pow(mean.z * k.inv_exposure, k.key));
+    if constexpr (MODE == TDK_TONEMAP_REINHARD) tm = mk3(tdk_div(c.x, ad.x + c.x), tdk_div(c.y, ad.y + c.y), tdk_div(c.z, ad.z + c.z));
+    else if constexpr (MODE == TDK_TONEMAP_LINEAR) tm = mk3(tdk_div(c.x, ad.x), tdk_div(c.y, ad.y), tdk_div(c.z, ad.z));
+    else tm = aces_fit(mk3(tdk_div(c.x, ad.x), tdk_div(c.y, ad.y), tdk_div(c.z, ad.z)));
   }
   const f3 g = mk3(tdk_pow(fmaxf(tm.x, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.y, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.z, 0.0f), k.inv_gamma));
   f3 o = cB::vibrance(g, k.vibrance);
@@ -165,12 +165,12 @@ __device__ __forceinline__ TmConst make_consts(const float* metrics, float gamma
   k.inv_gamma = 1.0f / gamma;
   k.vibrance = vibrance;
   k.light_adapt = light_adapt;
-  k.aces_scale = 1.0f; k.key = 1.0f; k.exposure = 1.0f; k.m0 = k.m1 = k.m2 = 0.0f;
+  k.aces_scale = 1.0f; k.key = 1.0f; k.inv_exposure = 1.0f; k.m0 = k.m1 = k.m2 = 0.0f;
   if constexpr (MODE == TDK_TONEMAP_ACES) {
     k.aces_scale = tdk_pow(2.0f, intensity);
   } else {
     k.key = map_key_of(metrics[0]);
-    k.exposure = tdk_exp(intensity);
+    k.inv_exposure = 1.0f / tdk_exp(intensity);
     k.m0 = metrics[2]; k.m1 = metrics[3]; k.m2 = metrics[4];
   }
   return k;
