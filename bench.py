@@ -62,8 +62,12 @@ def parse_args():
 def algorithmic_bytes_per_px(kernel: str, s: int) -> float | None:
     table = {
         'tdk_rcd(interior)': 1 * s + 3 * s,          # bayer in, rgb out
-        'tdk_wiener(tiles)': 1 * s + 1 * s,          # the Wiener op on one plane: plane in, plane out (finish kernel included)
+        # on the fused Wiener.process_log_luminance path the op boundary is RGB in, RGB out (the
+        # log-luminance planes are internal): SURVEY.md 8(d) "denoise 6 + 6 = 12 B/px" at fp16
+        'tdk_wiener(tiles)': 3 * s + 3 * s,
         'tdk_wiener(finish)': 1 * s + 1 * s,
+        'tdk_wiener(finish+modify)': 3 * s + 3 * s,
+        'tdk_bilateral(slice+modify)': 3 * s + 3 * s,
         'tdk_bilateral(splat)': 1 * s + 1 * s,       # the bilateral op on one plane
         'tdk_bilateral(blur_xy)': 1 * s + 1 * s,
         'tdk_bilateral(blur_z)': 1 * s + 1 * s,

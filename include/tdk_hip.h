@@ -133,11 +133,25 @@ size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_
 int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
                const float* sigmas, int dtype, tdk_stream_t stream);
 
+/* Wiener.process_log_luminance as ONE call (reference torch_darktable/denoise.py:54-58 composes
+ * compute_log_luminance -> Wiener.process -> modify_log_luminance): rgb (H,W,3) -> rgb (H,W,3).
+ * The log-luminance plane lives in the workspace in fp32 and its denoised version never reaches HBM.
+ * sigma: one device float. */
+size_t tdk_wiener_log_luminance_workspace_bytes(int width, int height, int tile_size, int overlap_factor);
+int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
+                             const float* sigma, float eps, int dtype, tdk_stream_t stream);
+
 /* ---- Bilateral.process: reference csrc/local_contrast/bilateral.cu:358-385 (extension.cpp:111-121) */
 int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]);
 size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
 int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
                   float detail, int dtype, tdk_stream_t stream);
+
+/* Bilateral.process_rgb / process_log_rgb as ONE call (reference torch_darktable/local_contrast.py:109-125:
+ * compute_[log_]luminance -> Bilateral.process -> modify_[log_]luminance). */
+size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
+int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
+                      int log_mode, float eps, int dtype, tdk_stream_t stream);
 
 /* ---- Laplacian.process: reference csrc/local_contrast/laplacian.cu:433-480 (extension.cpp:94-108).
  * num_gamma must be 6 (laplacian.cu:625-634). */

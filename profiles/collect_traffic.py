@@ -22,12 +22,14 @@ from collections import defaultdict
 # kernel function name fragment -> (TDK_LAUNCH name used by bench.py, loads are wide 16-B streams)
 KERNELS = {
     'wiener_tiles': ('tdk_wiener(tiles)', True),
-    'wiener_finish': ('tdk_wiener(finish)', False),
+    'wiener_finish_modify': ('tdk_wiener(finish+modify)', False),
+    'wiener_finish<': ('tdk_wiener(finish)', False),
     'rcd_interior': ('tdk_rcd(interior)', False),
     'rcd_border': ('tdk_rcd(border)', False),
     'splat_gather_kernel': ('tdk_bilateral(splat)', False),
     'blur_xy_kernel': ('tdk_bilateral(blur_xy)', False),
     'blur_z_kernel': ('tdk_bilateral(blur_z)', False),
+    'slice_modify_kernel': ('tdk_bilateral(slice+modify)', False),
     'slice_kernel': ('tdk_bilateral(slice)', False),
     # 8-B / 16-B per-lane streaming loads: calibrated on these kernels' known byte counts (12 MP fp16:
     # tonemap reads 75.5 MB, FETCH_SIZE reported 37.8 MB) -> the factor 2 applies to them as well

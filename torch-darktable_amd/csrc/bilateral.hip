@@ -19,7 +19,7 @@
 //  * slice: trilinear gather from the (L2/MALL-resident) grid, fp32 or fp16 planes.
 //  The zero-extended stencil forms below are bit-identical to the reference's edge-case
 //  formulas (x + 0 == x); and the gather sums in raster order, so the whole op is bit-identical to the oracle.
-#include "tdk_common.h"
+#include "tdk_color.h"
 
 namespace {
 
@@ -79,7 +79,11 @@ __device__ __forceinline__ float axis_weight(int p, float sigma_s, int size, int
   return (ib == cell) ? (1.0f - f) : ((ib == cell - 1) ? f : -1.0f);  // -1: no contribution
 }
 
-template <typename T>
+// MAXC = compile-time bound on the candidate window per axis (2 sigma_s + 5 pixels); columns whose
+// window is longer (large sigma_s, or the last column that also collects every clamped pixel)
+// take the generic loop.  Zero-weight pixels are skipped: every contribution is >= +0 and the
+// sums start at +0, so dropping exact zeros cannot change a bit.
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void splat_gather_kernel(const T* __restrict__ lum, float* __restrict__ grid, int width, int height, GridDims d,
                                                            float sigma_s, float sigma_r) {
   extern __shared__ float colacc[];  // [sz][256]
@@ -93,19 +97,35 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(const T* __restrict__
   const int x_hi = (cx == d.sx - 1) ? width - 1 : min(width - 1, (int)ceilf(sigma_s * (float)(cx + 1)) + 1);
   const int y_lo = max(0, (int)floorf(sigma_s * (float)(cy - 1)) - 1);
   const int y_hi = (cy == d.sy - 1) ? height - 1 : min(height - 1, (int)ceilf(sigma_s * (float)(cy + 1)) + 1);
-  for (int y = y_lo; y <= y_hi; y++) {
-    const float wy = axis_weight(y, sigma_s, d.sy, cy);
-    if (wy < 0.0f) continue;
-    for (int x = x_lo; x <= x_hi; x++) {
-      const float wx = axis_weight(x, sigma_s, d.sx, cx);
-      if (wx < 0.0f) continue;
-      const float L = ld(lum, (size_t)y * width + x);
-      const float gz = clampf(L / sigma_r, 0.0f, (float)(d.sz - 1));
-      const int iz = min((int)gz, d.sz - 2);
-      const float fz = gz - (float)iz;
-      const float wxy = wx * wy;
-      colacc[iz * 256 + tid] += wxy * (1.0f - fz) * contrib;
-      colacc[(iz + 1) * 256 + tid] += wxy * fz * contrib;
+
+  auto deposit = [&](int x, int y, float wxy) {
+    const float L = ld(lum, (size_t)y * width + x);
+    const float gz = clampf(L / sigma_r, 0.0f, (float)(d.sz - 1));
+    const int iz = min((int)gz, d.sz - 2);
+    const float fz = gz - (float)iz;
+    colacc[iz * 256 + tid] += wxy * (1.0f - fz) * contrib;
+    colacc[(iz + 1) * 256 + tid] += wxy * fz * contrib;
+  };
+
+  if (x_hi - x_lo + 1 <= MAXC) {
+    float wxs[MAXC];  // x weights are the same for every row: computed once, statically indexed
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) wxs[k] = (x_lo + k <= x_hi) ? axis_weight(x_lo + k, sigma_s, d.sx, cx) : -1.0f;
+    for (int y = y_lo; y <= y_hi; y++) {
+      const float wy = axis_weight(y, sigma_s, d.sy, cy);
+      if (!(wy > 0.0f)) continue;
+#pragma unroll
+      for (int k = 0; k < MAXC; k++)
+        if (wxs[k] > 0.0f) deposit(x_lo + k, y, wxs[k] * wy);
+    }
+  } else {
+    for (int y = y_lo; y <= y_hi; y++) {
+      const float wy = axis_weight(y, sigma_s, d.sy, cy);
+      if (!(wy > 0.0f)) continue;
+      for (int x = x_lo; x <= x_hi; x++) {
+        const float wx = axis_weight(x, sigma_s, d.sx, cx);
+        if (wx > 0.0f) deposit(x, y, wx * wy);
+      }
     }
   }
   const size_t plane = (size_t)d.sx * d.sy;
@@ -181,6 +201,69 @@ __global__ __launch_bounds__(256) void slice_kernel(const T* __restrict__ lum, c
   }
 }
 
+// Fused epilogue of Bilateral.process_rgb / process_log_rgb (reference local_contrast.py:109-125):
+// slice the grid at the pixel's (fp32) luminance and put the new lightness straight back into the
+// RGB pixel, so the filtered luminance plane is never written to HBM.
+template <typename T, bool LOG, int VEC>
+__global__ __launch_bounds__(256) void slice_modify_kernel(const float* __restrict__ lum, const float* __restrict__ grid, const T* __restrict__ rgb,
+                                                           T* __restrict__ out, int width, int height, GridDims d, float sigma_s, float sigma_r,
+                                                           float detail) {
+  const int64_t n = (int64_t)width * height / VEC;  // VEC == 4 requires width % 4 == 0
+  const float norm = -detail * sigma_r * 4.0f;
+  const size_t oy = d.sx, oz = (size_t)d.sx * d.sy;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < n; gi += (int64_t)gridDim.x * 256) {
+    const int64_t i0 = gi * VEC;
+    const int y = (int)(i0 / width), x0 = (int)(i0 - (int64_t)y * width);
+    float v[3 * VEC], Lv[VEC];
+    if constexpr (VEC == 4) {
+      rgb4_io<T>::load(rgb, (size_t)gi, v);
+      s4_io<float>::load(lum, (size_t)gi, Lv);
+    } else {
+      v[0] = ld(rgb, (size_t)i0 * 3); v[1] = ld(rgb, (size_t)i0 * 3 + 1); v[2] = ld(rgb, (size_t)i0 * 3 + 2);
+      Lv[0] = lum[i0];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const float L = Lv[k];
+      const Sample s = make_sample(x0 + k, y, L, d, sigma_s, sigma_r);
+      const float ax = 1.0f - s.fx, ay = 1.0f - s.fy, az = 1.0f - s.fz, bx = s.fx, by = s.fy, bz = s.fz;
+      const float* g = grid + s.ix + oy * s.iy + oz * s.iz;
+      const float Ldiff = g[0] * ax * ay * az + g[1] * bx * ay * az + g[oy] * ax * by * az + g[oy + 1] * bx * by * az + g[oz] * ax * ay * bz +
+                          g[oz + 1] * bx * ay * bz + g[oz + oy] * ax * by * bz + g[oz + oy + 1] * bx * by * bz;
+      const float Lnew = fmaxf(0.0f, L + norm * Ldiff);
+      const f3 c = mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+      const f3 r = LOG ? cA::modify_log_luminance(c, Lnew) : cA::modify_luminance(c, Lnew);
+      v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+    }
+    if constexpr (VEC == 4) rgb4_io<T>::store(out, (size_t)gi, v);
+    else { st(out, (size_t)i0 * 3, v[0]); st(out, (size_t)i0 * 3 + 1, v[1]); st(out, (size_t)i0 * 3 + 2, v[2]); }
+  }
+}
+
+// splat -> blur x,y -> z derivative; leaves the final grid in `grid`
+template <typename T>
+int build_grid(const T* in, float* grid, float* tmp, int width, int height, const GridDims& d, float sigma_s, float sigma_r, hipStream_t s) {
+  const size_t splat_lds = (size_t)d.sz * 256 * sizeof(float);
+  const dim3 sgrid(tdk_div_up(d.sx, 32), tdk_div_up(d.sy, 8));
+  if (2.0f * sigma_s + 5.0f <= 10.0f) {
+    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
+                 "tdk_bilateral(hipFuncSetAttribute)");
+    TDK_LAUNCH("tdk_bilateral(splat)", (splat_gather_kernel<T, 10>), sgrid, dim3(256), splat_lds, s, in, grid, width, height, d, sigma_s, sigma_r);
+  } else {
+    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
+                 "tdk_bilateral(hipFuncSetAttribute)");
+    TDK_LAUNCH("tdk_bilateral(splat)", (splat_gather_kernel<T, 24>), sgrid, dim3(256), splat_lds, s, in, grid, width, height, d, sigma_s, sigma_r);
+  }
+  TDK_LAUNCH("tdk_bilateral(blur_xy)", blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);
+  TDK_LAUNCH("tdk_bilateral(blur_z)", blur_z_kernel, dim3((unsigned)tdk_div_up64((int64_t)d.sx * d.sy, 256)), dim3(256), 0, s, tmp, grid, d);
+  return TDK_OK;
+}
+
+inline unsigned stream_blocks(int64_t npix) {
+  int64_t b = tdk_div_up64(npix, 256);
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
 template <typename T>
 int launch(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, hipStream_t s) {
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
@@ -188,18 +271,35 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
   float* grid = reinterpret_cast<float*>(workspace);
   float* tmp = grid + tdk_align_up(ncell, 64);
   const T* in = reinterpret_cast<const T*>(lum_in);
-  T* out = reinterpret_cast<T*>(lum_out);
-  const size_t splat_lds = (size_t)d.sz * 256 * sizeof(float);
-  TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
-               "tdk_bilateral(hipFuncSetAttribute)");
-  TDK_LAUNCH("tdk_bilateral(splat)", splat_gather_kernel<T>, dim3(tdk_div_up(d.sx, 32), tdk_div_up(d.sy, 8)), dim3(256), splat_lds, s, in, grid, width, height,
-             d, sigma_s, sigma_r);
-  TDK_LAUNCH("tdk_bilateral(blur_xy)", blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);
-  TDK_LAUNCH("tdk_bilateral(blur_z)", blur_z_kernel, dim3((unsigned)tdk_div_up64((int64_t)d.sx * d.sy, 256)), dim3(256), 0, s, tmp, grid, d);
-  const int64_t npix = (int64_t)width * height;
-  int64_t blocks = tdk_div_up64(npix, 256);
-  if (blocks > 4096) blocks = 4096;
-  TDK_LAUNCH("tdk_bilateral(slice)", slice_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, in, grid, out, width, height, d, sigma_s, sigma_r, detail);
+  const int rc = build_grid<T>(in, grid, tmp, width, height, d, sigma_s, sigma_r, s);
+  if (rc != TDK_OK) return rc;
+  TDK_LAUNCH("tdk_bilateral(slice)", slice_kernel<T>, dim3(stream_blocks((int64_t)width * height)), dim3(256), 0, s, in, grid, reinterpret_cast<T*>(lum_out),
+             width, height, d, sigma_s, sigma_r, detail);
+  return TDK_OK;
+}
+
+template <typename T>
+int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, int log_mode, float eps,
+               int dtype, hipStream_t s) {
+  const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
+  const size_t ncell = (size_t)d.sx * d.sy * d.sz;
+  float* grid = reinterpret_cast<float*>(workspace);
+  float* tmp = grid + tdk_align_up(ncell, 64);
+  float* plane = tmp + tdk_align_up(ncell, 64);
+  int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)width * height, log_mode, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(s));
+  if (rc != TDK_OK) return rc;
+  rc = build_grid<float>(plane, grid, tmp, width, height, d, sigma_s, sigma_r, s);
+  if (rc != TDK_OK) return rc;
+  const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
+  const unsigned blocks = stream_blocks((int64_t)width * height / (vec ? 4 : 1));
+  const T* rin = reinterpret_cast<const T*>(rgb_in);
+  T* rout = reinterpret_cast<T*>(rgb_out);
+#define TDK_SM(LOGV, VECV) \
+  TDK_LAUNCH("tdk_bilateral(slice+modify)", (slice_modify_kernel<T, LOGV, VECV>), dim3(blocks), dim3(256), 0, s, plane, grid, rin, rout, width, height, d, \
+             sigma_s, sigma_r, detail)
+  if (log_mode) { if (vec) TDK_SM(true, 4); else TDK_SM(true, 1); }
+  else { if (vec) TDK_SM(false, 4); else TDK_SM(false, 1); }
+#undef TDK_SM
   return TDK_OK;
 }
 
@@ -224,5 +324,21 @@ TDK_EXPORT int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace,
   TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
   TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral: sigmas must be positive");
   TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(lum_in, lum_out, workspace, width, height, sigma_s, sigma_r, detail, tdk_stream(stream)));
+  return TDK_OK;
+}
+
+TDK_EXPORT size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r) {
+  if (width <= 0 || height <= 0 || !(sigma_r > 0.0f)) return 0;
+  const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
+  return tdk_align_up((2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) + (size_t)width * height) * sizeof(float), 256);
+}
+
+TDK_EXPORT int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
+                                 int log_mode, float eps, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb_in && rgb_out && workspace, "tdk_bilateral_rgb: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
+  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_rgb: sigmas must be positive");
+  TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
+  TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, tdk_stream(stream)));
   return TDK_OK;
 }

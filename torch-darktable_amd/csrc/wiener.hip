@@ -28,7 +28,7 @@
 #include <math.h>
 #include <string.h>
 
-#include "tdk_common.h"
+#include "tdk_color.h"
 
 #pragma clang fp contract(fast)
 
@@ -341,6 +341,44 @@ __global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ s
   }
 }
 
+// Fused epilogue of Wiener.process_log_luminance (reference denoise.py:54-58): the slab fold and
+// normalisation of wiener_finish followed directly by modify_log_luminance on the RGB pixel, so the
+// denoised log-luminance plane is never written to HBM.  The colour math must not be contracted.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restrict__ slabs, const T* __restrict__ rgb, T* __restrict__ out, int W, int H,
+                                                            int s, int K, int jmin, int ngx, WParams prm) {
+#pragma clang fp contract(off)
+  const int64_t n = (int64_t)W * H / VEC;  // VEC == 4 requires W % 4 == 0: a group never straddles a row
+  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
+  const int u0 = -jmin * s;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
+    const int64_t i0 = g * VEC;
+    const int y = (int)(i0 / W), x0 = (int)(i0 - (int64_t)y * W);
+    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
+    const bool py = (offy < K - s) && gy > 0;
+    const float my = prm.m1[y % s];
+    float v[3 * VEC];
+    if constexpr (VEC == 4) rgb4_io<T>::load(rgb, (size_t)g, v);
+    else { v[0] = ld(rgb, (size_t)i0 * 3); v[1] = ld(rgb, (size_t)i0 * 3 + 1); v[2] = ld(rgb, (size_t)i0 * 3 + 2); }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const int x = x0 + k;
+      const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
+      const bool px = (offx < K - s) && gx > 0;
+      auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RSX * RSY) + (size_t)oy * RSX + ox]; };
+      float acc = slab_at(gx, gy, offx, offy);
+      if (px) acc += slab_at(gx - 1, gy, offx + BS, offy);
+      if (py) acc += slab_at(gx, gy - 1, offx, offy + BSY);
+      if (px && py) acc += slab_at(gx - 1, gy - 1, offx + BS, offy + BSY);
+      const float mask = prm.m1[x % s] * my;
+      const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc / (mask + 1e-15f));
+      v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+    }
+    if constexpr (VEC == 4) rgb4_io<T>::store(out, (size_t)g, v);
+    else { st(out, (size_t)i0 * 3, v[0]); st(out, (size_t)i0 * 3 + 1, v[1]); st(out, (size_t)i0 * 3 + 2, v[2]); }
+  }
+}
+
 void make_window(int K, double weight, float* w) {
   const double half = K / 2.0, scale = weight * half * half;
   double v[32], nrm = 0.0;
@@ -371,9 +409,7 @@ Geometry geometry(int W, int H, int K, int ov) {
   return g;
 }
 
-template <typename T, int K>
-int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
-  const Geometry g = geometry(W, H, K, ov);
+template <int K> WParams make_params(const Geometry& g, int ov) {
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
@@ -383,20 +419,56 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
     for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
     prm.m1[r] = m;
   }
-  float* slabs = reinterpret_cast<float*>(workspace);
+  return prm;
+}
+
+template <typename T, int K>
+int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, const float* sigmas, const Geometry& g, const WParams& prm, hipStream_t st_) {
   constexpr int TPW = 64 / K;
   const size_t lds_bytes = (size_t)NW * ((size_t)K * acc_stride(g.RSX) + TPW * K * (K + 1)) * sizeof(float);
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_wiener(hipFuncSetAttribute)");
-  const int64_t npix = (int64_t)W * H;
-  int64_t fin_blocks = tdk_div_up64(npix, 256);
-  if (fin_blocks > 4096) fin_blocks = 4096;
+  TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(64 * NW), lds_bytes, st_, in, slabs, W, H, C, c, g.s, ov, g.jmin, g.ntx,
+             g.nty, sigmas, prm);
+  return TDK_OK;
+}
+
+inline unsigned stream_blocks(int64_t npix) {
+  int64_t b = tdk_div_up64(npix, 256);
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+template <typename T, int K>
+int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
+  const Geometry g = geometry(W, H, K, ov);
+  const WParams prm = make_params<K>(g, ov);
+  float* slabs = reinterpret_cast<float*>(workspace);
   for (int c = 0; c < C; c++) {
-    TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(64 * NW), lds_bytes, st_, reinterpret_cast<const T*>(in), slabs, W, H,
-               C, c, g.s, ov, g.jmin, g.ntx, g.nty, sigmas, prm);
-    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)fin_blocks), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
+    const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
+    if (rc != TDK_OK) return rc;
+    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3(stream_blocks((int64_t)W * H)), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
                K, g.jmin, g.ngx, prm);
   }
+  return TDK_OK;
+}
+
+// Wiener.process_log_luminance as one call: extract log-L (fp32 plane in the workspace) -> tiles -> fused fold + modify.
+template <typename T, int K>
+int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_) {
+  const Geometry g = geometry(W, H, K, ov);
+  const WParams prm = make_params<K>(g, ov);
+  float* slabs = reinterpret_cast<float*>(workspace);
+  float* plane = slabs + tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY, 64);
+  int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
+  if (rc != TDK_OK) return rc;
+  rc = launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
+  if (rc != TDK_OK) return rc;
+  if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16))
+    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3(stream_blocks((int64_t)W * H / 4)), dim3(256), 0, st_, slabs,
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
+  else
+    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 1>), dim3(stream_blocks((int64_t)W * H)), dim3(256), 0, st_, slabs,
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
   return TDK_OK;
 }
 
@@ -420,5 +492,25 @@ TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width,
   hipStream_t s = tdk_stream(stream);
   if (tile_size == 16) TDK_DISPATCH_DTYPE(dtype, T, return (launch<T, 16>(in, out, workspace, width, height, channels, overlap_factor, sigmas, s)));
   TDK_DISPATCH_DTYPE(dtype, T, return (launch<T, 32>(in, out, workspace, width, height, channels, overlap_factor, sigmas, s)));
+  return TDK_OK;
+}
+
+TDK_EXPORT size_t tdk_wiener_log_luminance_workspace_bytes(int width, int height, int tile_size, int overlap_factor) {
+  const size_t slabs = tdk_wiener_workspace_bytes(width, height, 1, tile_size, overlap_factor);
+  if (slabs == 0) return 0;
+  const Geometry g = geometry(width, height, tile_size, overlap_factor);
+  return tdk_align_up((tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY, 64) + (size_t)width * height) * sizeof(float), 256);
+}
+
+TDK_EXPORT int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
+                                        const float* sigma, float eps, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb_in && rgb_out && workspace && sigma, "tdk_wiener_log_luminance: null pointer");
+  TDK_REQUIRE(tile_size == 16 || tile_size == 32, "tile_size must be 16 or 32, got %d", tile_size);
+  TDK_REQUIRE(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8, "overlap_factor must be 2, 4, or 8");
+  TDK_REQUIRE(width >= tile_size && height >= tile_size, "tdk_wiener_log_luminance: image %dx%d smaller than the tile size %d", width, height, tile_size);
+  TDK_REQUIRE(eps > 0.0f, "Epsilon must be positive");
+  hipStream_t s = tdk_stream(stream);
+  if (tile_size == 16) TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 16>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s)));
+  TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 32>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s)));
   return TDK_OK;
 }

@@ -63,8 +63,11 @@ class Wiener:
         return extension.modify_luminance(image, self.process(lum.unsqueeze(2), noise).squeeze(2))
 
     def process_log_luminance(self, image: torch.Tensor, noise, eps: float = 1e-4) -> torch.Tensor:
-        log_lum = extension.compute_log_luminance(image, eps=eps)
-        return extension.modify_log_luminance(image, self.process(log_lum.unsqueeze(2), noise).squeeze(2), eps=eps)
+        """Denoise the log-lightness of an RGB image (extract -> Wiener -> replace), fused in one library call."""
+        expected = (self._wiener.height, self._wiener.width, 3)
+        if tuple(image.shape) != expected:
+            raise RuntimeError(f'Wiener input shape {tuple(image.shape)} != expected {expected}')
+        return self._wiener.process_log_luminance(image, self._sigmas(noise, 1), eps)
 
     def process_log(self, image: torch.Tensor, noise, eps: float = 1e-4) -> torch.Tensor:
         return self.process((image + eps).log(), noise).exp()

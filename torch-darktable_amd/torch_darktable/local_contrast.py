@@ -72,12 +72,10 @@ class Bilateral:
 
     def process_rgb(self, input_image: torch.Tensor, detail: float) -> torch.Tensor:
         assert input_image.dim() == 3, f'image must have 3 dimensions, got {input_image.shape}'
-        lum = extension.compute_luminance(input_image)
-        return extension.modify_luminance(input_image, self.process(lum, float(detail)))
+        return self._bilateral.process_rgb(input_image, float(detail))  # extract -> filter -> replace, one library call
 
     def process_log_rgb(self, input_image: torch.Tensor, detail: float, eps: float = 1e-6) -> torch.Tensor:
-        log_lum = extension.compute_log_luminance(input_image, eps)
-        return extension.modify_log_luminance(input_image, self.process(log_lum, float(detail)), eps)
+        return self._bilateral.process_log_rgb(input_image, float(detail), eps)
 
     @property
     def image_size(self) -> tuple[int, int]:

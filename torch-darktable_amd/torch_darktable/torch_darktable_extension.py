@@ -506,6 +506,25 @@ class Wiener(_Workspace):
       check(lib.tdk_wiener(_ptr(x), _ptr(out), _ptr(self._ws), w, h, c, self._tile_size, self._overlap_factor, _ptr(sig), _dtype_tag(x), _stream()))
     return out
 
+  def process_log_luminance(self, image: torch.Tensor, noise_sigmas: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+    """Fused form of the reference wrapper's compute_log_luminance -> process -> modify_log_luminance
+    (torch_darktable/denoise.py:54-58): one library call, the log-luminance planes stay in fp32
+    scratch and the denoised one is consumed in place."""
+    _check_rgb(image, 'image', allow_half=True)
+    _require(image.device == self._device, 'input device mismatch')
+    _require(image.size(0) == self._height and image.size(1) == self._width, 'Input dimensions must match workspace size')
+    _require(eps > 0.0, 'Epsilon must be positive')
+    x = image.contiguous()
+    sig = noise_sigmas.to(device=x.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      nbytes = lib.tdk_wiener_log_luminance_workspace_bytes(self._width, self._height, self._tile_size, self._overlap_factor)
+      if self._ws is None or self._ws.numel() < nbytes:
+        self._ws = _workspace(max(nbytes, 256), x.device)
+      check(lib.tdk_wiener_log_luminance(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._tile_size, self._overlap_factor,
+                                         _ptr(sig), float(eps), _dtype_tag(x), _stream()))
+    return out
+
 
 # ------------------------------------------------------------------ local contrast
 class Bilateral(_Workspace):
@@ -549,11 +568,34 @@ class Bilateral(_Workspace):
     x = luminance.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      if self._ws is None:
-        self._ws = _workspace(lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      nbytes = lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r)
+      if self._ws is None or self._ws.numel() < nbytes:
+        self._ws = _workspace(nbytes, x.device)
       check(lib.tdk_bilateral(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
                               _dtype_tag(x), _stream()))
     return out
+
+  def _process_rgb(self, image: torch.Tensor, detail: float, log_mode: bool, eps: float) -> torch.Tensor:
+    _check_rgb(image, 'image', allow_half=True)
+    _require(image.size(0) == self._height and image.size(1) == self._width, 'Input shape must match (H,W)')
+    x = image.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+      nbytes = lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r)
+      if self._ws is None or self._ws.numel() < nbytes:
+        self._ws = _workspace(nbytes, x.device)
+      check(lib.tdk_bilateral_rgb(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+                                  int(log_mode), float(eps), _dtype_tag(x), _stream()))
+    return out
+
+  def process_rgb(self, image: torch.Tensor, detail: float) -> torch.Tensor:
+    """Fused compute_luminance -> process -> modify_luminance (reference local_contrast.py:109-114)."""
+    return self._process_rgb(image, detail, False, 1e-6)
+
+  def process_log_rgb(self, image: torch.Tensor, detail: float, eps: float = 1e-6) -> torch.Tensor:
+    """Fused compute_log_luminance -> process -> modify_log_luminance (reference local_contrast.py:116-125)."""
+    _require(eps > 0.0, 'Epsilon must be positive')
+    return self._process_rgb(image, detail, True, eps)
 
 
 class Laplacian(_Workspace):
