@@ -30,7 +30,7 @@ namespace {
 
 constexpr int TW = 64, TH = 64, HALO = 10;
 constexpr int RW = TW + 2 * HALO, RH = TH + 2 * HALO;  // 84 x 84 working region
-constexpr int S = RW + 1;                               // LDS row stride (odd)
+constexpr int S = RW + 2;                               // LDS row stride: even, so lanes that alternate between two rows stay on distinct banks
 constexpr int PLANE = RH * S;
 constexpr int NT = 1024;
 
@@ -115,12 +115,15 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
     }
   }
   {
-    constexpr int K = 7, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
-    for (int i = tid; i < SW2 * SH; i += NT) {
-      const int rr = i / SW2, ci = i - rr * SW2;
-      const int r = rr + HALO - K;
+    // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
+    // on the row whose R/B sites have that column parity -> conflict-free LDS rows (stride S even)
+    constexpr int K = 7, SW = TW + 2 * K, SHB = (TH + 2 * K) / 2;
+    for (int i = tid; i < SW * SHB; i += NT) {
+      const int bnd = i / SW, cc = i - bnd * SW;
+      const int c = (HALO - K) + cc;
+      const int ra = (HALO - K) + 2 * bnd;
+      const int r = ra + (((c & 1) ^ rb_par(gy0 + ra)) & 1);
       const int gy = gy0 + r;
-      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
       const int gx = gx0 + c;
       float v = 0.0f;
       if (gy >= 2 && gy <= h - 2 && gx >= 2 && gx <= w - 2) {
@@ -135,12 +138,15 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
   // ---- P3: step 3.1 (green at R/B sites, halo 5 -> pE at the green partner) and
   //          step 4.1 (p/q_diff at odd columns, halo 6 -> pB)
   {
-    constexpr int K = 5, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
-    for (int i = tid; i < SW2 * SH; i += NT) {
-      const int rr = i / SW2, ci = i - rr * SW2;
-      const int r = rr + HALO - K;
+    // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
+    // on the row whose R/B sites have that column parity -> conflict-free LDS rows (stride S even)
+    constexpr int K = 5, SW = TW + 2 * K, SHB = (TH + 2 * K) / 2;
+    for (int i = tid; i < SW * SHB; i += NT) {
+      const int bnd = i / SW, cc = i - bnd * SW;
+      const int c = (HALO - K) + cc;
+      const int ra = (HALO - K) + 2 * bnd;
+      const int r = ra + (((c & 1) ^ rb_par(gy0 + ra)) & 1);
       const int gy = gy0 + r;
-      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
       const int gx = gx0 + c;
       float g = 0.0f;
       if (gy >= 4 && gy <= h - 5 && gx >= 4 && gx <= w - 5) {
@@ -194,12 +200,15 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
 
   // ---- P4: step 4.2 (PQ_dir at R/B sites, halo 4 -> pE, replacing lpf)
   {
-    constexpr int K = 4, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
-    for (int i = tid; i < SW2 * SH; i += NT) {
-      const int rr = i / SW2, ci = i - rr * SW2;
-      const int r = rr + HALO - K;
+    // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
+    // on the row whose R/B sites have that column parity -> conflict-free LDS rows (stride S even)
+    constexpr int K = 4, SW = TW + 2 * K, SHB = (TH + 2 * K) / 2;
+    for (int i = tid; i < SW * SHB; i += NT) {
+      const int bnd = i / SW, cc = i - bnd * SW;
+      const int c = (HALO - K) + cc;
+      const int ra = (HALO - K) + 2 * bnd;
+      const int r = ra + (((c & 1) ^ rb_par(gy0 + ra)) & 1);
       const int gy = gy0 + r;
-      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ rb_par(gy));
       const int gx = gx0 + c;
       float pq = 0.0f;
       if (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3) {
@@ -216,13 +225,16 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
 
   // ---- P5: step 5.1 (opposite colour at R/B sites, halo 3 -> pC)
   {
-    constexpr int K = 3, SW2 = (TW + 2 * K) / 2, SH = TH + 2 * K;
-    for (int i = tid; i < SW2 * SH; i += NT) {
-      const int rr = i / SW2, ci = i - rr * SW2;
-      const int r = rr + HALO - K;
+    // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
+    // on the row whose R/B sites have that column parity -> conflict-free LDS rows (stride S even)
+    constexpr int K = 3, SW = TW + 2 * K, SHB = (TH + 2 * K) / 2;
+    for (int i = tid; i < SW * SHB; i += NT) {
+      const int bnd = i / SW, cc = i - bnd * SW;
+      const int c = (HALO - K) + cc;
+      const int ra = (HALO - K) + 2 * bnd;
+      const int r = ra + (((c & 1) ^ rb_par(gy0 + ra)) & 1);
       const int gy = gy0 + r;
-      const int par = rb_par(gy);
-      const int c = (HALO - K) + 2 * ci + (((HALO - K) & 1) ^ par);
+      const int par = c & 1;
       const int gx = gx0 + c;
       float val = 0.0f;
       if (gy >= 4 && gy <= h - 4 && gx >= 4 && gx <= w - 4) {
@@ -256,27 +268,36 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
   }
   __syncthreads();
 
-  // ---- P6: step 5.2 at green sites + write_output (margin 7)
+  // ---- P6: step 5.2 at green sites + write_output (margin 7), half a tile (32 rows) at a time.
+  // Compute pass: one lane per COLUMN of a 2-row band (checkerboard, as above) produces the
+  // band's green site and R/B site of that column and parks the finished pixels in an LDS staging
+  // area (the p/q plane is dead by now); store pass: one lane per 4 consecutive pixels reads
+  // 48 contiguous staged bytes and writes them with 16-B global stores.
   {
-    const int lx = (tid & 15) * 4, ly = tid >> 4;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < w && y >= 7 && y < h - 7) {
-      const int r = ly + HALO;
-      const int par = rb_par(y);
-      const int row_color = cfa_color(y, par, pattern);  // colour of this row's R/B sites (0 or 2)
-      float px[12];
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int gx = x + k;
-        const int c = lx + k + HALO;
-        const int q = r * S + c;
-        float R, G, B;
-        if ((gx & 1) == par) {  // R/B site
+    constexpr int STG = TW * 3 + 4;  // staging row stride in floats (16-B aligned rows)
+    float* stg = pB;
+    static_assert(32 * STG <= PLANE, "staging must fit in one plane");
+    for (int half = 0; half < 2; half++) {
+      {
+        const int bnd = tid >> 6, cc = tid & 63;
+        const int ty_a = half * 32 + 2 * bnd;            // tile-local first row of the band
+        const int c = cc + HALO;
+        const int par_a = rb_par(y0 + ty_a);             // R/B column parity of row ty_a
+        const int rb_off = ((c & 1) ^ par_a) & 1;        // row (0/1 inside the band) of this column's R/B site
+        // --- R/B site: native, green from step 3.1, other colour from step 5.1
+        {
+          const int ty = ty_a + rb_off, r = ty + HALO, q = r * S + c;
+          const int row_color = cfa_color(y0 + ty, c & 1, pattern);  // colour of this row's R/B sites
           const float native = pA[q], green = pE[r * S + (c ^ 1)], other = pC[q];
-          G = green;
-          if (row_color == 0) { R = native; B = other; } else { B = native; R = other; }
-        } else {  // green site: step 5.2
+          float* o = stg + (ty - half * 32) * STG + cc * 3;
+          o[0] = fmaxf(row_color == 0 ? native : other, 0.0f);
+          o[1] = fmaxf(green, 0.0f);
+          o[2] = fmaxf(row_color == 0 ? other : native, 0.0f);
+        }
+        // --- green site: step 5.2
+        {
+          const int ty = ty_a + (rb_off ^ 1), r = ty + HALO, q = r * S + c;
+          const int row_color = cfa_color(y0 + ty, (c & 1) ^ 1, pattern);  // colour of this row's R/B sites (left/right neighbours)
           const float eps = 1e-5f;
           const float VH_c = pD[q];
           const float VH_n = 0.25f * (pD[q - S - 1] + pD[q - S + 1] + pD[q + S - 1] + pD[q + S + 1]);
@@ -314,27 +335,36 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
             const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
             res[ci] = g + mixf(V_Est, H_Est, VH_Disc);
           }
-          R = res[0]; G = g; B = res[1];
+          float* o = stg + (ty - half * 32) * STG + cc * 3;
+          o[0] = fmaxf(res[0], 0.0f);
+          o[1] = fmaxf(g, 0.0f);
+          o[2] = fmaxf(res[1], 0.0f);
         }
-        px[3 * k] = fmaxf(R, 0.0f);
-        px[3 * k + 1] = fmaxf(G, 0.0f);
-        px[3 * k + 2] = fmaxf(B, 0.0f);
-        any |= (gx >= 7 && gx < w - 7);
       }
-      if (any) {
-        const bool all_in = (x >= 7) && (x + 3 < w - 7);
-        if (all_in) {
-          store_rgb4(out, x, y, w, vec_ok, px);
-        } else {
-          for (int k = 0; k < 4; k++) {
-            const int gx = x + k;
-            if (gx >= 7 && gx < w - 7) {
-              const size_t p = (size_t)y * w + gx;
-              st(out, p * 3, px[3 * k]); st(out, p * 3 + 1, px[3 * k + 1]); st(out, p * 3 + 2, px[3 * k + 2]);
+      __syncthreads();
+      if (tid < 512) {
+        const int ly = tid >> 4, lx = (tid & 15) * 4;
+        const int x = x0 + lx, y = y0 + half * 32 + ly;
+        if (x < w && y >= 7 && y < h - 7 && x + 3 >= 7 && x < w - 7) {
+          float px[12];
+          const float4* sp = reinterpret_cast<const float4*>(stg + ly * STG + lx * 3);
+          const float4 a = sp[0], b = sp[1], c4 = sp[2];
+          px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+          px[8] = c4.x; px[9] = c4.y; px[10] = c4.z; px[11] = c4.w;
+          if ((x >= 7) && (x + 3 < w - 7)) {
+            store_rgb4(out, x, y, w, vec_ok, px);
+          } else {
+            for (int k = 0; k < 4; k++) {
+              const int gx = x + k;
+              if (gx >= 7 && gx < w - 7) {
+                const size_t p = (size_t)y * w + gx;
+                st(out, p * 3, px[3 * k]); st(out, p * 3 + 1, px[3 * k + 1]); st(out, p * 3 + 2, px[3 * k + 2]);
+              }
             }
           }
         }
       }
+      __syncthreads();
     }
   }
 }

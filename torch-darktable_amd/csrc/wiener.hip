@@ -194,9 +194,9 @@ __host__ __device__ inline int acc_stride(int n) {
 // deterministic, unlike the reference's atomic overlap-add.
 template <typename T, int K>
 __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan,
-                                                        int s, int ov, int jmin, int ntile_x, int ntile_y, const float* __restrict__ sigmas,
-                                                        WParams prm) {
-  constexpr int TPW = 64 / K;  // tiles per wave
+                                                        int s, int ov, int jmin, int ntile_x, int ntile_y, int ngx, int ngroups,
+                                                        const float* __restrict__ sigmas, WParams prm) {
+  constexpr int TPW = 64 / K;  // tile pairs (slots) per wave
   extern __shared__ __align__(16) float lds[];
   const int GTX = TPW * ov;
   const int RSX = BS - s + K, RSY = (NW - 1) * s + K;
@@ -207,114 +207,149 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   float* tbuf = acc + K * AST;         // per-wave transpose scratch
   const int row = lane & (K - 1), slot = lane / K;
   float* my_t = tbuf + slot * (K * (K + 1));
-
-  for (int i = lane; i < K * AST; i += 64) acc[i] = 0.0f;
-
   const float sigma = sigmas[chan];
   const float sig2 = sigma * sigma;
-  const int jx0 = jmin + blockIdx.x * GTX, jy0 = jmin + blockIdx.y * NW;  // first tile origin index of the group
-  const int jy = jy0 + wave;
-  const int oy = jy * s;
-  const bool row_active = jy < jmin + ntile_y;
-  const int sy = reflect_index(oy + row, H);
-  const T* src_row = img + (size_t)sy * W * C;
   const int partner = (lane & ~(K - 1)) | ((K - row) & (K - 1));  // lane holding column -kx of the same slot
+  const float wy = prm.wf[row], iy = prm.wi[row];
+  const int nsteps = ov >> 1;
 
-  // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
-  // the spectra are separated with the Hermitian identities A[k] = (Z[k] + conj(Z[-k])) / 2,
-  // B[k] = (Z[k] - conj(Z[-k])) / 2i (Z[-k] sits in lane -kx, register -ky), each gets its own
-  // Wiener gain, and Z' = A' + i B' goes back through one inverse transform: re = a', im = b'.
-  // Tile a / b of slot i in step `base`: columns i*ov + 2*base (+1).  The a (b) tiles of
-  // different slots are ov columns apart, and a and b are accumulated one after the other, so
-  // the plain read-modify-writes below never collide.
-  for (int base = 0; base < (ov >> 1); base++) {
-    const int txa = slot * ov + 2 * base, txb = txa + 1;
-    const bool act_a = row_active && (jx0 + txa < jmin + ntile_x);
-    const bool act_b = row_active && (jx0 + txb < jmin + ntile_x);
-    const int oxa = (jx0 + txa) * s, oxb = (jx0 + txb) * s;
-
-    float re[K], im[K];
-    float mean_a = 0.0f, mean_b = 0.0f;
-    const float wy = prm.wf[row];
-    if (act_a) {
-      load_row<T, K>(src_row, oxa, W, C, chan, re);
+  // Work item = (group, step).  Persistent workgroups (one per CU: the LDS footprint allows no
+  // more) walk the groups with a grid stride; the rows of the NEXT item are fetched into
+  // registers while the current one is transformed, so HBM/L2 latency never sits on the
+  // critical path of the 2-waves-per-SIMD schedule.
+  struct Item {
+    int txa, txb, oxa, oxb;
+    bool act_a, act_b;
+    const T* src_row;
+  };
+  auto make_item = [&](int grp, int base) {
+    Item it;
+    const int gx = grp % ngx, gy = grp / ngx;
+    const int jx0 = jmin + gx * GTX, jy = jmin + gy * NW + wave;
+    const bool row_active = (grp < ngroups) && (jy < jmin + ntile_y);
+    it.txa = slot * ov + 2 * base;
+    it.txb = it.txa + 1;
+    it.act_a = row_active && (jx0 + it.txa < jmin + ntile_x);
+    it.act_b = row_active && (jx0 + it.txb < jmin + ntile_x);
+    it.oxa = (jx0 + it.txa) * s;
+    it.oxb = (jx0 + it.txb) * s;
+    it.src_row = img + (size_t)reflect_index(jy * s + row, H) * W * C;
+    return it;
+  };
+  auto fetch = [&](const Item& it, float (&ra)[K], float (&rb)[K]) {
+    if (it.act_a) {
+      load_row<T, K>(it.src_row, it.oxa, W, C, chan, ra);
     } else {
 #pragma unroll
-      for (int k = 0; k < K; k++) re[k] = 0.0f;
+      for (int k = 0; k < K; k++) ra[k] = 0.0f;
     }
-    if (act_b) {
-      load_row<T, K>(src_row, oxb, W, C, chan, im);
+    if (it.act_b) {
+      load_row<T, K>(it.src_row, it.oxb, W, C, chan, rb);
     } else {
 #pragma unroll
-      for (int k = 0; k < K; k++) im[k] = 0.0f;
+      for (int k = 0; k < K; k++) rb[k] = 0.0f;
     }
-    {
-      float sa = 0.0f, sb = 0.0f;
+  };
+
+#ifndef TDK_WIENER_PREFETCH
+#define TDK_WIENER_PREFETCH 0
+#endif
+  float nre[K], nim[K];  // prefetched rows of the next item
+  Item cur = make_item((int)blockIdx.x, 0);
+  if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    for (int i = lane; i < K * AST; i += 64) acc[i] = 0.0f;
+
+    // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
+    // the spectra are separated with the Hermitian identities A[k] = (Z[k] + conj(Z[-k])) / 2,
+    // B[k] = (Z[k] - conj(Z[-k])) / 2i (Z[-k] sits in lane -kx, register -ky), each gets its own
+    // Wiener gain, and Z' = A' + i B' goes back through one inverse transform: re = a', im = b'.
+    // Tile a / b of slot i in step `base`: columns i*ov + 2*base (+1).  The a (b) tiles of
+    // different slots are ov columns apart, and a and b are accumulated one after the other, so
+    // the plain read-modify-writes below never collide.
+    for (int base = 0; base < nsteps; base++) {
+      float re[K], im[K];
+      const Item it = cur;
+      if (TDK_WIENER_PREFETCH) {
 #pragma unroll
-      for (int k = 0; k < K; k++) { sa += re[k]; sb += im[k]; }
-#pragma unroll
-      for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
-      mean_a = sa / (float)(K * K);
-      mean_b = sb / (float)(K * K);
-#pragma unroll
-      for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
-        re[k] = ((re[k] - mean_a) * wy) * prm.wf[k];
-        im[k] = ((im[k] - mean_b) * wy) * prm.wf[k];
+        for (int k = 0; k < K; k++) { re[k] = nre[k]; im[k] = nim[k]; }
+      } else {
+        fetch(it, re, im);
       }
-    }
+      // issue the next item's loads now; they complete under the transforms below
+      cur = (base + 1 < nsteps) ? make_item(grp, base + 1) : make_item(grp + (int)gridDim.x, 0);
+      if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
 
-    fft_inreg<K, false>(re, im);            // along x
-    transpose_tile<K>(re, my_t, row);
-    transpose_tile<K>(im, my_t, row);
-    fft_inreg<K, false>(re, im);            // along y (lane = kx)
-
-    // separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  Index k and
-    // its mirror K-k are handled together so the partner lane still sees the untouched values.
-    auto shrink = [&](float zr, float zi, float pr, float pi, float& outr, float& outi) {
-      const float ar = 0.5f * (zr + pr), ai = 0.5f * (zi - pi);
-      const float br = 0.5f * (zi + pi), bi = -0.5f * (zr - pr);
-      const float pa = (ar * ar + ai * ai) + 1e-15f, pb = (br * br + bi * bi) + 1e-15f;
-      const float ga = fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa);
-      const float gb = fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb);
-      outr = ga * ar - gb * bi;
-      outi = ga * ai + gb * br;
-    };
+      float mean_a, mean_b;
+      {
+        float sa = 0.0f, sb = 0.0f;
 #pragma unroll
-    for (int k = 0; k <= K / 2; k++) {
-      const int k2 = (K - k) & (K - 1);
-      const float p_k2_r = __shfl(re[k2], partner, 64), p_k2_i = __shfl(im[k2], partner, 64);  // Z[-k] for index k
-      const float p_k_r = __shfl(re[k], partner, 64), p_k_i = __shfl(im[k], partner, 64);      // Z[-k2] for index k2
-      float r0, i0, r1, i1;
-      shrink(re[k], im[k], p_k2_r, p_k2_i, r0, i0);
-      shrink(re[k2], im[k2], p_k_r, p_k_i, r1, i1);
-      re[k] = r0; im[k] = i0;
-      if (k2 != k) { re[k2] = r1; im[k2] = i1; }
-    }
+        for (int k = 0; k < K; k++) { sa += re[k]; sb += im[k]; }
+#pragma unroll
+        for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+        mean_a = sa / (float)(K * K);
+        mean_b = sb / (float)(K * K);
+#pragma unroll
+        for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
+          re[k] = ((re[k] - mean_a) * wy) * prm.wf[k];
+          im[k] = ((im[k] - mean_b) * wy) * prm.wf[k];
+        }
+      }
 
-    fft_inreg<K, true>(re, im);             // inverse along y
-    transpose_tile<K>(re, my_t, row);
-    transpose_tile<K>(im, my_t, row);
-    fft_inreg<K, true>(re, im);             // inverse along x (lane = y again): re = tile a, im = tile b
+      fft_inreg<K, false>(re, im);            // along x
+      transpose_tile<K>(re, my_t, row);
+      transpose_tile<K>(im, my_t, row);
+      fft_inreg<K, false>(re, im);            // along y (lane = kx)
 
-    const float iy = prm.wi[row];
-    if (act_a) accumulate_row<K>(acc + row * AST + txa * s, re, mean_a, wy, iy, prm, (s & 3) == 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (act_b) accumulate_row<K>(acc + row * AST + txb * s, im, mean_b, wy, iy, prm, (s & 3) == 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  // fold the private accumulators: slab row r gets wave w's row r - w*s, for 0 <= r - w*s < K
-  float* slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(RSX * RSY);
-  for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
-    const int r = i / RSX, c = i - r * RSX;
-    float v = 0.0f;
-    for (int w = 0; w < NW; w++) {
-      const int rr = r - w * s;
-      if (rr >= 0 && rr < K) v += lds[w * per_wave + rr * AST + c];
+      // separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  Index k and
+      // its mirror K-k are handled together so the partner lane still sees the untouched values.
+      auto shrink = [&](float zr, float zi, float pr, float pi, float& outr, float& outi) {
+        const float ar = 0.5f * (zr + pr), ai = 0.5f * (zi - pi);
+        const float br = 0.5f * (zi + pi), bi = -0.5f * (zr - pr);
+        const float pa = (ar * ar + ai * ai) + 1e-15f, pb = (br * br + bi * bi) + 1e-15f;
+        const float ga = fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa);
+        const float gb = fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb);
+        outr = ga * ar - gb * bi;
+        outi = ga * ai + gb * br;
+      };
+#pragma unroll
+      for (int k = 0; k <= K / 2; k++) {
+        const int k2 = (K - k) & (K - 1);
+        const float p_k2_r = __shfl(re[k2], partner, 64), p_k2_i = __shfl(im[k2], partner, 64);  // Z[-k] for index k
+        const float p_k_r = __shfl(re[k], partner, 64), p_k_i = __shfl(im[k], partner, 64);      // Z[-k2] for index k2
+        float r0, i0, r1, i1;
+        shrink(re[k], im[k], p_k2_r, p_k2_i, r0, i0);
+        shrink(re[k2], im[k2], p_k_r, p_k_i, r1, i1);
+        re[k] = r0; im[k] = i0;
+        if (k2 != k) { re[k2] = r1; im[k2] = i1; }
+      }
+
+      fft_inreg<K, true>(re, im);             // inverse along y
+      transpose_tile<K>(re, my_t, row);
+      transpose_tile<K>(im, my_t, row);
+      fft_inreg<K, true>(re, im);             // inverse along x (lane = y again): re = tile a, im = tile b
+
+      if (it.act_a) accumulate_row<K>(acc + row * AST + it.txa * s, re, mean_a, wy, iy, prm, (s & 3) == 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (it.act_b) accumulate_row<K>(acc + row * AST + it.txb * s, im, mean_b, wy, iy, prm, (s & 3) == 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    slab[i] = v;
+    __syncthreads();
+    // fold the private accumulators: slab row r gets wave w's row r - w*s, for 0 <= r - w*s < K
+    float* slab = slabs + (size_t)grp * (size_t)(RSX * RSY);
+    for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
+      const int r = i / RSX, c = i - r * RSX;
+      float v = 0.0f;
+      for (int w = 0; w < NW; w++) {
+        const int rr = r - w * s;
+        if (rr >= 0 && rr < K) v += lds[w * per_wave + rr * AST + c];
+      }
+      slab[i] = v;
+    }
+    __syncthreads();  // the accumulators are zeroed again at the top of the loop
   }
 }
 
@@ -428,8 +463,12 @@ int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, 
   const size_t lds_bytes = (size_t)NW * ((size_t)K * acc_stride(g.RSX) + TPW * K * (K + 1)) * sizeof(float);
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_wiener(hipFuncSetAttribute)");
-  TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(g.ngx, g.ngy), dim3(64 * NW), lds_bytes, st_, in, slabs, W, H, C, c, g.s, ov, g.jmin, g.ntx,
-             g.nty, sigmas, prm);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ngroups = g.ngx * g.ngy;
+  const int blocks = ngroups < cus ? ngroups : cus;  // persistent: one workgroup per CU (LDS-limited), grid-stride over the groups
+  TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(blocks), dim3(64 * NW), lds_bytes, st_, in, slabs, W, H, C, c, g.s, ov, g.jmin, g.ntx,
+             g.nty, g.ngx, ngroups, sigmas, prm);
   return TDK_OK;
 }
 
