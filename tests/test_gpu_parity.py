@@ -310,3 +310,47 @@ def test_fp16_storage_pipeline(td, oracle, dev, scene):
     u8 = td.reinhard_tonemap(rgb16, m, td.TonemapParameters(0.75, 2.0, 1.0, 0.0))
     ref_u8 = oracle.tonemap('reinhard', npy(rgb16).astype(np.float32), npy(m), 0.75, 2.0, 1.0, 0.0)
     assert np.abs(npy(u8).astype(np.int32) - ref_u8.astype(np.int32)).max() <= 1
+
+
+# ------------------------------------------------------------------ pipeline (caller + on-disk format)
+def test_image_processor_end_to_end(td, oracle, dev, scene, tmp_path):
+    """packed 12-bit raw FILE with trailing padding -> ImageProcessor -> uint8, against the oracle
+    chain decode -> white balance -> RCD -> postprocess -> normalise -> Wiener -> bilateral -> ACES."""
+    from torch_darktable.pipeline import CameraSettings, ImageProcessingSettings, ImageProcessor, ImageTransform, ToneMapper
+    from torch_darktable.pipeline.camera_settings import load_raw_bytes
+
+    h, w, pad = 96, 128, 64
+    bayer = np.clip(oracle.mosaic(scene(h, w, 31), oracle.RGGB)[:, :, 0], 0, 1)
+    packed = oracle.encode12_f32(bayer.ravel(), False, True)
+    raw_file = tmp_path / 'cam' / 'frame0.raw'
+    raw_file.parent.mkdir()
+    raw_file.write_bytes(packed.tobytes() + bytes(pad))
+    settings = ImageProcessingSettings(tone_gamma=2.2, tone_intensity=1.0, moving_average=1.0, postprocess=True, enable_bilateral=True,
+                                       tone_mapping=ToneMapper.aces, vibrance=0.3)
+    cam = CameraSettings(name='cam', image_size=(w, h), padding=pad, white_balance=(1.5, 1.0, 1.2), image_processing=settings,
+                         transform=ImageTransform.rotate_270)
+    assert raw_file.stat().st_size == cam.bytes
+    proc = ImageProcessor.from_camera_settings(cam, dev)
+    out = proc.process(load_raw_bytes(raw_file, dev), 'cam')
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (w, h, 3)  # rotated
+
+    b = oracle.decode12_f32(packed, False, True).reshape(h, w)
+    b = oracle.apply_white_balance(b, [1.5, 1.0, 1.2], oracle.RGGB)
+    rgb = oracle.postprocess(oracle.rcd(b, oracle.RGGB), oracle.RGGB, 3, False, True, 0.04)
+    bounds = oracle.image_bounds([rgb], 8)
+    rgb = (rgb - bounds[0]) / (bounds[1] - bounds[0])
+    ll = oracle.compute_luminance(rgb, True, 1e-4)
+    rgb = oracle.modify_luminance(rgb, oracle.wiener(ll[:, :, None], 0.075, 32, 4)[:, :, 0], True)
+    rgb = oracle.modify_luminance(rgb, oracle.bilateral(oracle.compute_luminance(rgb), 2.0, 0.2, 0.4))
+    ref = oracle.tonemap('aces', rgb, None, 2.2, 1.0, 1.0, 0.3)
+    ref = np.rot90(ref, 3, (0, 1))
+    d = np.abs(npy(out).astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 2 and (d > 0).mean() < 0.02, f'max {d.max()} frac {(d > 0).mean()}'
+
+    with pytest.raises(Exception) as ei:
+        proc.process(load_raw_bytes(raw_file, dev)[:-1], 'cam')
+    assert 'mismatch' in str(ei.value)
+    # moving average: a second identical frame leaves the statistics unchanged
+    m0 = proc.metrics.clone()
+    proc.process(load_raw_bytes(raw_file, dev), 'cam')
+    assert torch.allclose(proc.metrics, m0)
