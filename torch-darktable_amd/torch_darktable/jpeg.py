@@ -1,11 +1,32 @@
-"""JPEG front-end names (reference torch_darktable/jpeg.py).  The reference wraps nvjpeg; the
-MI355X build has no GPU encoder (out of the kernel hot path), so `Jpeg.encode` raises."""
+"""JPEG front-end (reference torch_darktable/jpeg.py).  The reference wraps nvjpeg; here the encoder
+is a host (Pillow / libjpeg-turbo) backend behind the same API -- see extension.Jpeg."""
+
+from enum import IntEnum
 
 from .extension import extension
 
-Jpeg = extension.Jpeg
 JpegException = extension.JpegException
-InputFormat = extension.JpegInputFormat
-Subsampling = extension.JpegSubsampling
+
+
+class InputFormat(IntEnum):
+    BGR = extension.JpegInputFormat.BGR
+    RGB = extension.JpegInputFormat.RGB
+    BGRI = extension.JpegInputFormat.BGRI
+    RGBI = extension.JpegInputFormat.RGBI
+
+
+class Subsampling(IntEnum):
+    CSS_444 = extension.JpegSubsampling.CSS_444
+    CSS_422 = extension.JpegSubsampling.CSS_422
+    CSS_GRAY = extension.JpegSubsampling.CSS_GRAY
+
+
+class Jpeg:
+    def __init__(self):
+        self.jpeg = extension.Jpeg()
+
+    def encode(self, image, quality=94, input_format=InputFormat.RGBI, subsampling=Subsampling.CSS_422, progressive=False):
+        return self.jpeg.encode(image, quality, int(input_format), int(subsampling), progressive)
+
 
 __all__ = ['InputFormat', 'Jpeg', 'JpegException', 'Subsampling']

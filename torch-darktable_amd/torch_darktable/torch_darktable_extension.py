@@ -628,30 +628,64 @@ class Laplacian(_Workspace):
     return out
 
 
-# ------------------------------------------------------------------ JPEG (out of the kernel hot path)
+# ------------------------------------------------------------------ JPEG (after the hot path)
 class JpegException(Exception):
   pass
 
 
 class JpegInputFormat(enum.IntEnum):
-  BGR = 3
-  RGB = 4
-  BGRI = 5
-  RGBI = 6
+  """reference csrc/jpeg_encoder.h (enum order)"""
+
+  BGR = 0
+  RGB = 1
+  BGRI = 2
+  RGBI = 3
 
 
 class JpegSubsampling(enum.IntEnum):
   CSS_444 = 0
   CSS_422 = 1
-  CSS_GRAY = 6
+  CSS_GRAY = 2
 
 
 class Jpeg:
-  """The reference wraps nvjpeg (csrc/jpeg_encoder.cu); there is no HIP kernel to write and no
-  ROCm codec is assumed, so encoding is not part of this build (next-row 8f-4)."""
+  """Same call signature and result type (CPU uint8 tensor holding the JPEG bitstream) as the
+  reference's nvjpeg wrapper (csrc/jpeg_encoder.cu:104-180).  There is no ROCm counterpart of
+  nvjpeg in this environment and no HIP kernel to write, so this is a HOST encoder (Pillow /
+  libjpeg-turbo, optimised Huffman tables like the reference): it copies the uint8 image to the
+  host first.  It is not part of the measured kernel hot path; bit-identity with nvjpeg output is
+  neither expected nor testable here (parity unpinned)."""
 
-  def encode(self, image, quality, input_format, subsampling, progressive):
-    raise JpegException('JPEG encoding is not available in the MI355X build (out of the kernel hot path)')
+  def encode(self, image: torch.Tensor, quality: int, input_format: int, subsampling: int, progressive: bool) -> torch.Tensor:
+    import io
+
+    from PIL import Image
+
+    if image.dtype != torch.uint8:
+      raise RuntimeError('Input image should be uint8')
+    if not image.is_contiguous():
+      raise RuntimeError('Input data should be contiguous')
+    fmt, sub = JpegInputFormat(int(input_format)), JpegSubsampling(int(subsampling))
+    try:
+      arr = image.detach().cpu()
+      if fmt in (JpegInputFormat.BGR, JpegInputFormat.RGB):  # planar (3, H, W)
+        arr = arr.permute(1, 2, 0)
+      if arr.dim() != 3 or arr.size(2) != 3:
+        raise JpegException(f'expected a 3-channel image, got shape {tuple(image.shape)}')
+      if fmt in (JpegInputFormat.BGR, JpegInputFormat.BGRI):
+        arr = arr.flip(2)
+      pil = Image.fromarray(arr.contiguous().numpy(), 'RGB')
+      buf = io.BytesIO()
+      if sub == JpegSubsampling.CSS_GRAY:
+        pil.convert('L').save(buf, 'JPEG', quality=int(quality), optimize=True, progressive=bool(progressive))
+      else:
+        pil.save(buf, 'JPEG', quality=int(quality), optimize=True, progressive=bool(progressive),
+                 subsampling='4:4:4' if sub == JpegSubsampling.CSS_444 else '4:2:2')
+    except JpegException:
+      raise
+    except Exception as e:  # noqa: BLE001
+      raise JpegException(f'JPEG encode failed: {e}') from e
+    return torch.frombuffer(bytearray(buf.getvalue()), dtype=torch.uint8)
 
   def __repr__(self) -> str:
     return 'Jpeg'
