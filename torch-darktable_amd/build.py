@@ -29,6 +29,9 @@ CXXFLAGS = ['-O3', '-std=c++17', f'--offload-arch={ARCH}', '-ffp-contract=off', 
             '-Wall', '-Wno-unused-function']
 
 
+CXXFLAGS += os.environ.get('TDK_EXTRA_FLAGS', '').split()  # experiments: e.g. TDK_EXTRA_FLAGS=-DTDK_WIENER_SHARED_ACC=1
+
+
 def _stale(target: Path, deps) -> bool:
   return (not target.exists()) or any(d.stat().st_mtime > target.stat().st_mtime for d in deps)
 

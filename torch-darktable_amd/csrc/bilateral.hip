@@ -19,6 +19,8 @@
 //  * slice: trilinear gather from the (L2/MALL-resident) grid, fp32 or fp16 planes.
 //  The zero-extended stencil forms below are bit-identical to the reference's edge-case
 //  formulas (x + 0 == x); and the gather sums in raster order, so the whole op is bit-identical to the oracle.
+#include <stdlib.h>
+
 #include "tdk_color.h"
 
 namespace {
@@ -240,6 +242,285 @@ __global__ __launch_bounds__(256) void slice_modify_kernel(const float* __restri
   }
 }
 
+// ---- the whole op in one tile kernel (small sigma_s) -------------------------------------------
+// For small sigma_s the grid is as large as the image (12 MP, sigma_s 2, sigma_r 0.2: 2049 x 1537 x 6
+// floats = 76 MB) and the four-kernel path moves it through HBM five times.  Here one workgroup owns
+// a FTW x FTH pixel tile: it builds, in LDS, exactly the grid cells its pixels slice from (+2 cells
+// of blur halo), from the luminance of the tile (+ the pixels that splat into those cells), runs the
+// three blurs in LDS and slices straight into the output.  The grid never exists in HBM.
+// Every cell value is computed by the same expressions, in the same order, as in the kernels above
+// (raster-order gather, x then y then z), so the result is bit-identical to the four-kernel path.
+// Requires that no pixel is clamped onto the last grid column/row (host-checked): then a cell only
+// collects pixels within sigma_s of it and the tile's pixel halo is bounded.
+constexpr int FTW = 64, FTH = 32, FNT = 512;
+
+struct AxisTile {
+  int c_lo;  // first cell kept in LDS (2 below the first cell sliced; may be negative = outside the grid)
+  int nc;    // cells kept
+  int p_lo;  // first pixel whose splat can reach those cells
+  int np;    // pixels
+};
+
+// Shared by host (LDS sizing) and device: plain IEEE float ops, so both sides agree exactly.
+__host__ __device__ inline AxisTile axis_tile(int p0, int tile, int size_px, int size_cells, float sigma_s) {
+  const int p1 = ((p0 + tile < size_px) ? p0 + tile : size_px) - 1;
+  const float top = (float)(size_cells - 1);
+  const float g0 = fminf(fmaxf((float)p0 / sigma_s, 0.0f), top), g1 = fminf(fmaxf((float)p1 / sigma_s, 0.0f), top);
+  const int c0 = ((int)g0 < size_cells - 2) ? (int)g0 : size_cells - 2;
+  const int c1 = (((int)g1 < size_cells - 2) ? (int)g1 : size_cells - 2) + 1;
+  AxisTile t;
+  t.c_lo = c0 - 2;
+  t.nc = c1 - c0 + 5;
+  const int lo = (int)floorf(sigma_s * (float)(t.c_lo - 1)) - 1;
+  const int hi = (int)ceilf(sigma_s * (float)(c1 + 3)) + 1;
+  t.p_lo = lo > 0 ? lo : 0;
+  t.np = ((hi < size_px - 1) ? hi : size_px - 1) - t.p_lo + 1;
+  return t;
+}
+
+struct TileLds {
+  int rs;      // LDS grid row stride in cells (odd: a wave walking rows or columns never bank-conflicts)
+  int plane;   // floats per z-slice of the LDS grid (>= rs * max nc_y, multiple of 64: bank == column)
+  int usize;   // floats in the sample-tile / blur-temp union
+  int lw, lh;  // max pixels per axis in the sample tile
+};
+
+// i / n for 0 <= i < 2^20, 0 < n < 2^10 with inv = 1.0f / n: (i + 0.5) / n is at least 0.5 / n away
+// from an integer, far more than the float rounding error, so the truncation is exact.
+__device__ __forceinline__ int fast_div(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
+// MODE 0: luminance plane in (TL == T) -> filtered plane out; 1 / 2: fp32 plane + RGB in -> RGB out (linear / log)
+template <typename TL, typename T, int MODE, int VEC, int MAXC>
+__global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restrict__ lum, const T* __restrict__ rgb, T* __restrict__ out, int width,
+                                                            int height, GridDims d, float sigma_s, float sigma_r, float detail, int tiles_x,
+                                                            int ntiles, TileLds L) {
+  extern __shared__ float smem[];
+  float* A = smem;                      // [sz][plane] grid, cell (lx, ly) at ly * RS + lx
+  float* U = A + d.sz * L.plane;        // z sample coordinate of every pixel of the tile + halo, then blur temp
+  float* gxs = U + L.usize;             // x sample coordinate of pixel column p_lo + i
+  float* gys = gxs + L.lw;
+
+  // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles
+  const int chunk = gridDim.x >> 3;
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int x0 = txi * FTW, y0 = tyi * FTH;
+  const AxisTile ax = axis_tile(x0, FTW, width, d.sx, sigma_s), ay = axis_tile(y0, FTH, height, d.sy, sigma_s);
+  const int tid = threadIdx.x;
+  const int PS = L.plane, RS = L.rs, LWS = ax.np;
+  const float ztop = (float)(d.sz - 1);
+
+  for (int i = tid; i < ax.np; i += FNT) gxs[i] = clampf((float)(ax.p_lo + i) / sigma_s, 0.0f, (float)(d.sx - 1));
+  for (int i = tid; i < ay.np; i += FNT) gys[i] = clampf((float)(ay.p_lo + i) / sigma_s, 0.0f, (float)(d.sy - 1));
+  {
+    const float inv_np = 1.0f / (float)ax.np;
+    const TL* src = lum + (size_t)ay.p_lo * width + ax.p_lo;
+    for (int i = tid; i < ax.np * ay.np; i += FNT) {
+      const int r = fast_div(i, inv_np), c = i - r * ax.np;
+      U[i] = clampf(ld(src, (size_t)r * width + c) / sigma_r, 0.0f, ztop);  // make_sample's gz
+    }
+  }
+  for (int i = tid; i < d.sz * PS; i += FNT) A[i] = 0.0f;
+  __syncthreads();
+
+  // ---- splat (gather, raster order per column; same expressions as splat_gather_kernel)
+  const float contrib = 1.0f / (sigma_s * sigma_s);
+  {
+    const int ncol = ax.nc * ay.nc;
+    const float inv_nc = 1.0f / (float)ax.nc;
+    for (int c = tid; c < ncol; c += FNT) {
+      const int ly = fast_div(c, inv_nc), lx = c - ly * ax.nc;
+      const int cx = ax.c_lo + lx, cy = ay.c_lo + ly;
+      if (cx < 0 || cy < 0 || cx >= d.sx || cy >= d.sy) continue;
+      const int xa = max(ax.p_lo, (int)floorf(sigma_s * (float)(cx - 1)) - 1) - ax.p_lo;
+      const int xb = min(ax.p_lo + ax.np - 1, (int)ceilf(sigma_s * (float)(cx + 1)) + 1) - ax.p_lo;
+      const int ya = max(ay.p_lo, (int)floorf(sigma_s * (float)(cy - 1)) - 1) - ay.p_lo;
+      const int yb = min(ay.p_lo + ay.np - 1, (int)ceilf(sigma_s * (float)(cy + 1)) + 1) - ay.p_lo;
+      float* acc = A + ly * RS + lx;
+      // weight of a pixel with sample coordinate g on `cell` of an axis with `size` cells (-1: none)
+      auto weight = [](float g, int size, int cell) {
+        const int ib = min((int)g, size - 2);
+        const float f = g - (float)ib;
+        return (ib == cell) ? (1.0f - f) : ((ib == cell - 1) ? f : -1.0f);
+      };
+      auto deposit = [&](int rx, int ry, float wxy) {
+        const float gz = U[ry * LWS + rx];
+        const int iz = min((int)gz, d.sz - 2);
+        const float fz = gz - (float)iz;
+        acc[iz * PS] += wxy * (1.0f - fz) * contrib;
+        acc[(iz + 1) * PS] += wxy * fz * contrib;
+      };
+      if (xb - xa + 1 <= MAXC) {
+        float wxs[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) wxs[k] = (xa + k <= xb) ? weight(gxs[xa + k], d.sx, cx) : -1.0f;
+        for (int ry = ya; ry <= yb; ry++) {
+          const float wy = weight(gys[ry], d.sy, cy);
+          if (!(wy > 0.0f)) continue;
+#pragma unroll
+          for (int k = 0; k < MAXC; k++)
+            if (wxs[k] > 0.0f) deposit(xa + k, ry, wxs[k] * wy);
+        }
+      } else {
+        for (int ry = ya; ry <= yb; ry++) {
+          const float wy = weight(gys[ry], d.sy, cy);
+          if (!(wy > 0.0f)) continue;
+          for (int rx = xa; rx <= xb; rx++) {
+            const float wx = weight(gxs[rx], d.sx, cx);
+            if (wx > 0.0f) deposit(rx, ry, wx * wy);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- blur x: A -> U, one thread per (z, row) with a register window (cells beyond the LDS tile
+  // read as zero; they only feed cells nobody slices)
+  const float w0 = 6.0f / 16.0f, w1 = 4.0f / 16.0f, w2 = 1.0f / 16.0f;
+  {
+    const float inv_ncy = 1.0f / (float)ay.nc;
+    for (int row = tid; row < d.sz * ay.nc; row += FNT) {
+      const int z = fast_div(row, inv_ncy), ly = row - z * ay.nc;
+      const float* p = A + z * PS + ly * RS;
+      float* q = U + z * PS + ly * RS;
+      float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[1];  // nc >= 6
+      for (int lx = 0; lx < ax.nc; lx++) {
+        const float p2 = (lx + 2 < ax.nc) ? p[lx + 2] : 0.0f;
+        q[lx] = c0 * w0 + w1 * (p1 + m1) + w2 * (p2 + m2);
+        m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- blur y: U -> A, one thread per (z, column)
+  {
+    const float inv_ncx = 1.0f / (float)ax.nc;
+    for (int cc = tid; cc < d.sz * ax.nc; cc += FNT) {
+      const int z = fast_div(cc, inv_ncx), lx = cc - z * ax.nc;
+      const float* p = U + z * PS + lx;
+      float* q = A + z * PS + lx;
+      float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[RS];
+      for (int ly = 0; ly < ay.nc; ly++) {
+        const float p2 = (ly + 2 < ay.nc) ? p[(ly + 2) * RS] : 0.0f;
+        q[ly * RS] = c0 * w0 + w1 * (p1 + m1) + w2 * (p2 + m2);
+        m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- z derivative, in place (register window), one thread per column
+  for (int c = tid; c < RS * ay.nc; c += FNT) {
+    float* p = A + c;
+    const float v1 = 4.0f / 16.0f, v2 = 2.0f / 16.0f;
+    float m2 = 0.0f, m1 = 0.0f, c0 = p[0];
+    float p1 = (d.sz > 1) ? p[PS] : 0.0f;
+    for (int z = 0; z < d.sz; z++) {
+      const float p2 = (z + 2 < d.sz) ? p[(z + 2) * PS] : 0.0f;
+      p[z * PS] = v1 * (p1 - m1) + v2 * (p2 - m2);
+      m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+    }
+  }
+  __syncthreads();
+
+  // ---- slice (+ put the new lightness back into the pixel)
+  const float norm = -detail * sigma_r * 4.0f;
+  constexpr int GW = FTW / VEC;
+  for (int g = tid; g < GW * FTH; g += FNT) {
+    const int py = g / GW, y = y0 + py, x = x0 + (g - py * GW) * VEC;
+    if (x >= width || y >= height) continue;
+    const size_t i0 = (size_t)y * width + x;
+    float Lv[VEC], o[MODE == 0 ? VEC : 3 * VEC];
+    if constexpr (VEC == 4) {
+      s4_io<TL>::load(lum, i0 >> 2, Lv);
+      if constexpr (MODE != 0) rgb4_io<T>::load(rgb, i0 >> 2, o);
+    } else {
+      Lv[0] = ld(lum, i0);
+      if constexpr (MODE != 0) { o[0] = ld(rgb, i0 * 3); o[1] = ld(rgb, i0 * 3 + 1); o[2] = ld(rgb, i0 * 3 + 2); }
+    }
+    const float gy = gys[y - ay.p_lo];
+    const int iy = min((int)gy, d.sy - 2);
+    const float by = gy - (float)iy, ayw = 1.0f - by;
+    const float* grow = A + (iy - ay.c_lo) * RS - ax.c_lo;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const float Lp = Lv[k];
+      const float gx = gxs[x + k - ax.p_lo];
+      const int ix = min((int)gx, d.sx - 2);
+      const float bx = gx - (float)ix, axw = 1.0f - bx;
+      const float gz = clampf(Lp / sigma_r, 0.0f, ztop);
+      const int iz = min((int)gz, d.sz - 2);
+      const float bz = gz - (float)iz, azw = 1.0f - bz;
+      const int oy = RS, oz = PS;
+      const float* gp = grow + iz * PS + ix;
+      const float Ldiff = gp[0] * axw * ayw * azw + gp[1] * bx * ayw * azw + gp[oy] * axw * by * azw + gp[oy + 1] * bx * by * azw +
+                          gp[oz] * axw * ayw * bz + gp[oz + 1] * bx * ayw * bz + gp[oz + oy] * axw * by * bz + gp[oz + oy + 1] * bx * by * bz;
+      const float Lnew = fmaxf(0.0f, Lp + norm * Ldiff);
+      if constexpr (MODE == 0) {
+        o[k] = Lnew;
+      } else {
+        const f3 c = mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]);
+        const f3 r = (MODE == 2) ? cA::modify_log_luminance(c, Lnew) : cA::modify_luminance(c, Lnew);
+        o[3 * k] = r.x; o[3 * k + 1] = r.y; o[3 * k + 2] = r.z;
+      }
+    }
+    if constexpr (MODE == 0) {
+      if constexpr (VEC == 4) s4_io<T>::store(out, i0 >> 2, o);
+      else st(out, i0, o[0]);
+    } else {
+      if constexpr (VEC == 4) rgb4_io<T>::store(out, i0 >> 2, o);
+      else { st(out, i0 * 3, o[0]); st(out, i0 * 3 + 1, o[1]); st(out, i0 * 3 + 2, o[2]); }
+    }
+  }
+}
+
+constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;  // two workgroups per CU
+
+// Decide whether the tile kernel applies and size its LDS.  Returns false -> four-kernel path.
+static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, TileLds* L, size_t* lds_bytes) {
+  if (getenv("TDK_BILATERAL_NO_FUSE")) return false;
+  if (!(sigma_s >= 1.0f && sigma_s <= 4.0f)) return false;
+  // no pixel may be clamped onto the last column / row (those columns collect far-away pixels)
+  if ((float)(width - 1) / sigma_s > (float)(d.sx - 1) || (float)(height - 1) / sigma_s > (float)(d.sy - 1)) return false;
+  int ncx = 0, ncy = 0, lw = 0, lh = 0;
+  for (int x0 = 0; x0 < width; x0 += FTW) {
+    const AxisTile t = axis_tile(x0, FTW, width, d.sx, sigma_s);
+    ncx = t.nc > ncx ? t.nc : ncx; lw = t.np > lw ? t.np : lw;
+  }
+  for (int y0 = 0; y0 < height; y0 += FTH) {
+    const AxisTile t = axis_tile(y0, FTH, height, d.sy, sigma_s);
+    ncy = t.nc > ncy ? t.nc : ncy; lh = t.np > lh ? t.np : lh;
+  }
+  L->rs = ncx | 1;
+  L->plane = (int)tdk_align_up((size_t)L->rs * ncy, 64);
+  const int lt = lw * lh, bt = d.sz * L->plane;
+  L->usize = (int)tdk_align_up((size_t)(lt > bt ? lt : bt), 64);
+  L->lw = lw; L->lh = lh;
+  *lds_bytes = ((size_t)d.sz * L->plane + L->usize + (size_t)lw + (size_t)lh) * sizeof(float);
+  return *lds_bytes <= FUSED_LDS_LIMIT;
+}
+
+template <typename TL, typename T, int MODE>
+int launch_tiles(const TL* lum, const T* rgb, T* out, int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail,
+                 const TileLds& L, size_t lds_bytes, bool vec, hipStream_t s) {
+  const int tiles_x = tdk_div_up(width, FTW), ntiles = tiles_x * tdk_div_up(height, FTH);
+  const dim3 grid(8 * tdk_div_up(ntiles, 8));
+#define TDK_BT(VECV, MAXCV)                                                                                                                       \
+  do {                                                                                                                                            \
+    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>),                             \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "tdk_bilateral(hipFuncSetAttribute)");          \
+    TDK_LAUNCH("tdk_bilateral(tiles)", (bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), grid, dim3(FNT), lds_bytes, s, lum, rgb, out, width, height, d, \
+               sigma_s, sigma_r, detail, tiles_x, ntiles, L);                                                                                     \
+  } while (0)
+  // candidate pixels per axis of one grid column: <= 2 sigma_s + 5, exactly 2 sigma_s + 3 for integer sigma_s
+  const bool narrow = (2.0f * sigma_s + 5.0f <= 8.0f) || (sigma_s == floorf(sigma_s) && 2.0f * sigma_s + 3.0f <= 8.0f);
+  if (narrow) { if (vec) TDK_BT(4, 8); else TDK_BT(1, 8); }
+  else { if (vec) TDK_BT(4, 14); else TDK_BT(1, 14); }
+#undef TDK_BT
+  return TDK_OK;
+}
+
 // splat -> blur x,y -> z derivative; leaves the final grid in `grid`
 template <typename T>
 int build_grid(const T* in, float* grid, float* tmp, int width, int height, const GridDims& d, float sigma_s, float sigma_r, hipStream_t s) {
@@ -271,6 +552,12 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
   float* grid = reinterpret_cast<float*>(workspace);
   float* tmp = grid + tdk_align_up(ncell, 64);
   const T* in = reinterpret_cast<const T*>(lum_in);
+  TileLds L;
+  size_t lds_bytes = 0;
+  if (lum_in != lum_out && plan_tiles(width, height, d, sigma_s, &L, &lds_bytes)) {  // tiles read a pixel halo: not in place
+    const bool vec = (width % 4) == 0 && tdk_aligned(lum_in, 16) && tdk_aligned(lum_out, 16);
+    return launch_tiles<T, T, 0>(in, nullptr, reinterpret_cast<T*>(lum_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+  }
   const int rc = build_grid<T>(in, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
   TDK_LAUNCH("tdk_bilateral(slice)", slice_kernel<T>, dim3(stream_blocks((int64_t)width * height)), dim3(256), 0, s, in, grid, reinterpret_cast<T*>(lum_out),
@@ -288,9 +575,15 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
   float* plane = tmp + tdk_align_up(ncell, 64);
   int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)width * height, log_mode, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(s));
   if (rc != TDK_OK) return rc;
+  const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
+  TileLds L;
+  size_t lds_bytes = 0;
+  if (plan_tiles(width, height, d, sigma_s, &L, &lds_bytes)) {
+    if (log_mode) return launch_tiles<float, T, 2>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+    return launch_tiles<float, T, 1>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+  }
   rc = build_grid<float>(plane, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
-  const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
   const unsigned blocks = stream_blocks((int64_t)width * height / (vec ? 4 : 1));
   const T* rin = reinterpret_cast<const T*>(rgb_in);
   T* rout = reinterpret_cast<T*>(rgb_out);
