@@ -68,6 +68,7 @@ def algorithmic_bytes_per_px(kernel: str, s: int) -> float | None:
         'tdk_wiener(finish)': 1 * s + 1 * s,
         'tdk_wiener(finish+modify)': 3 * s + 3 * s,
         'tdk_bilateral(slice+modify)': 3 * s + 3 * s,
+        'tdk_bilateral(tiles)': 3 * s + 3 * s,       # fused op on the process_rgb path: RGB in, RGB out
         'tdk_bilateral(splat)': 1 * s + 1 * s,       # the bilateral op on one plane
         'tdk_bilateral(blur_xy)': 1 * s + 1 * s,
         'tdk_bilateral(blur_z)': 1 * s + 1 * s,

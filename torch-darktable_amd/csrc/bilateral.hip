@@ -283,7 +283,22 @@ struct TileLds {
   int plane;   // floats per z-slice of the LDS grid (>= rs * max nc_y, multiple of 64: bank == column)
   int usize;   // floats in the sample-tile / blur-temp union
   int lw, lh;  // max pixels per axis in the sample tile
+  int ncx, ncy;  // max cells per axis
 };
+
+// x / c for a divisor c that is constant over the launch, rc = 1.0f / c (correctly rounded, host):
+// q = RN(x * rc), r = x - q * c exactly (fma), q' = RN(q + r * rc) is the correctly rounded
+// quotient (Markstein) as long as nothing under- or overflows -- 3 instructions instead of the
+// ~12 of v_div_scale / v_rcp / Newton / v_div_fixup.  Outside the safe range: the real division.
+__device__ __forceinline__ float div_by(float x, float c, float rc) {
+  const float ax = fabsf(x);
+  const bool safe = (ax >= 0x1p-40f && ax <= 0x1p40f) || x == 0.0f;
+  // wave-uniform test so that the compiler keeps a real (never taken) branch instead of computing both
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(safe && c >= 0x1p-20f && c <= 0x1p20f)) != 0, 0)) return x / c;
+  const float q = x * rc;
+  const float r = __builtin_fmaf(-q, c, x);
+  return __builtin_fmaf(r, rc, q);
+}
 
 // i / n for 0 <= i < 2^20, 0 < n < 2^10 with inv = 1.0f / n: (i + 0.5) / n is at least 0.5 / n away
 // from an integer, far more than the float rounding error, so the truncation is exact.
@@ -299,6 +314,10 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
   float* U = A + d.sz * L.plane;        // z sample coordinate of every pixel of the tile + halo, then blur temp
   float* gxs = U + L.usize;             // x sample coordinate of pixel column p_lo + i
   float* gys = gxs + L.lw;
+  float* WX = U + L.lw * L.lh;          // (tail of U, dead before the blur) [nc_x][MAXC] splat weight of candidate pixel k on cell column lx (-1: none)
+  float* WY = WX + L.ncx * MAXC;
+  int* xa_t = reinterpret_cast<int*>(WY + L.ncy * MAXC);  // first candidate pixel (tile-relative) of a cell column; -1: outside the grid
+  int* ya_t = xa_t + L.ncx;
 
   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles
   const int chunk = gridDim.x >> 3;
@@ -309,16 +328,36 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
   const AxisTile ax = axis_tile(x0, FTW, width, d.sx, sigma_s), ay = axis_tile(y0, FTH, height, d.sy, sigma_s);
   const int tid = threadIdx.x;
   const int PS = L.plane, RS = L.rs, LWS = ax.np;
-  const float ztop = (float)(d.sz - 1);
+  const float ztop = (float)(d.sz - 1), rc_r = 1.0f / sigma_r;
 
-  for (int i = tid; i < ax.np; i += FNT) gxs[i] = clampf((float)(ax.p_lo + i) / sigma_s, 0.0f, (float)(d.sx - 1));
-  for (int i = tid; i < ay.np; i += FNT) gys[i] = clampf((float)(ay.p_lo + i) / sigma_s, 0.0f, (float)(d.sy - 1));
+  const float rc_s = 1.0f / sigma_s;
+  for (int i = tid; i < ax.np; i += FNT) gxs[i] = clampf(div_by((float)(ax.p_lo + i), sigma_s, rc_s), 0.0f, (float)(d.sx - 1));
+  for (int i = tid; i < ay.np; i += FNT) gys[i] = clampf(div_by((float)(ay.p_lo + i), sigma_s, rc_s), 0.0f, (float)(d.sy - 1));
+  // per-axis splat tables: a pixel with sample coordinate g (base cell ib, fraction f) gives cell ib
+  // the weight 1 - f and cell ib + 1 the weight f (axis_weight above)
+  auto axis_tables = [&](const AxisTile& t, int size_px, int size_cells, float* W, int* first) {
+    for (int i = tid; i < t.nc * MAXC; i += FNT) {
+      const int l = i / MAXC, k = i - l * MAXC, cell = t.c_lo + l;
+      float w = -1.0f;
+      int a = -1;
+      if (cell >= 0 && cell < size_cells) {
+        a = max(t.p_lo, (int)floorf(sigma_s * (float)(cell - 1)) - 1);
+        const int b = min(t.p_lo + t.np - 1, (int)ceilf(sigma_s * (float)(cell + 1)) + 1);
+        if (a + k <= b) w = axis_weight(a + k, sigma_s, size_cells, cell);
+        a -= t.p_lo;
+      }
+      W[i] = w;
+      if (k == 0) first[l] = a;
+    }
+  };
+  axis_tables(ax, width, d.sx, WX, xa_t);
+  axis_tables(ay, height, d.sy, WY, ya_t);
   {
     const float inv_np = 1.0f / (float)ax.np;
     const TL* src = lum + (size_t)ay.p_lo * width + ax.p_lo;
     for (int i = tid; i < ax.np * ay.np; i += FNT) {
       const int r = fast_div(i, inv_np), c = i - r * ax.np;
-      U[i] = clampf(ld(src, (size_t)r * width + c) / sigma_r, 0.0f, ztop);  // make_sample's gz
+      U[i] = clampf(div_by(ld(src, (size_t)(r * width + c)), sigma_r, rc_r), 0.0f, ztop);  // make_sample's gz
     }
   }
   for (int i = tid; i < d.sz * PS; i += FNT) A[i] = 0.0f;
@@ -331,44 +370,25 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
     const float inv_nc = 1.0f / (float)ax.nc;
     for (int c = tid; c < ncol; c += FNT) {
       const int ly = fast_div(c, inv_nc), lx = c - ly * ax.nc;
-      const int cx = ax.c_lo + lx, cy = ay.c_lo + ly;
-      if (cx < 0 || cy < 0 || cx >= d.sx || cy >= d.sy) continue;
-      const int xa = max(ax.p_lo, (int)floorf(sigma_s * (float)(cx - 1)) - 1) - ax.p_lo;
-      const int xb = min(ax.p_lo + ax.np - 1, (int)ceilf(sigma_s * (float)(cx + 1)) + 1) - ax.p_lo;
-      const int ya = max(ay.p_lo, (int)floorf(sigma_s * (float)(cy - 1)) - 1) - ay.p_lo;
-      const int yb = min(ay.p_lo + ay.np - 1, (int)ceilf(sigma_s * (float)(cy + 1)) + 1) - ay.p_lo;
+      const int xa = xa_t[lx], ya = ya_t[ly];
+      if (xa < 0 || ya < 0) continue;  // cell outside the grid: stays zero
       float* acc = A + ly * RS + lx;
-      // weight of a pixel with sample coordinate g on `cell` of an axis with `size` cells (-1: none)
-      auto weight = [](float g, int size, int cell) {
-        const int ib = min((int)g, size - 2);
-        const float f = g - (float)ib;
-        return (ib == cell) ? (1.0f - f) : ((ib == cell - 1) ? f : -1.0f);
-      };
-      auto deposit = [&](int rx, int ry, float wxy) {
-        const float gz = U[ry * LWS + rx];
-        const int iz = min((int)gz, d.sz - 2);
-        const float fz = gz - (float)iz;
-        acc[iz * PS] += wxy * (1.0f - fz) * contrib;
-        acc[(iz + 1) * PS] += wxy * fz * contrib;
-      };
-      if (xb - xa + 1 <= MAXC) {
-        float wxs[MAXC];
+      float wxs[MAXC];
 #pragma unroll
-        for (int k = 0; k < MAXC; k++) wxs[k] = (xa + k <= xb) ? weight(gxs[xa + k], d.sx, cx) : -1.0f;
-        for (int ry = ya; ry <= yb; ry++) {
-          const float wy = weight(gys[ry], d.sy, cy);
-          if (!(wy > 0.0f)) continue;
+      for (int k = 0; k < MAXC; k++) wxs[k] = WX[lx * MAXC + k];
+      const float* urow = U + ya * LWS + xa;
+      for (int j = 0; j < MAXC; j++, urow += LWS) {
+        const float wy = WY[ly * MAXC + j];
+        if (!(wy > 0.0f)) continue;
 #pragma unroll
-          for (int k = 0; k < MAXC; k++)
-            if (wxs[k] > 0.0f) deposit(xa + k, ry, wxs[k] * wy);
-        }
-      } else {
-        for (int ry = ya; ry <= yb; ry++) {
-          const float wy = weight(gys[ry], d.sy, cy);
-          if (!(wy > 0.0f)) continue;
-          for (int rx = xa; rx <= xb; rx++) {
-            const float wx = weight(gxs[rx], d.sx, cx);
-            if (wx > 0.0f) deposit(rx, ry, wx * wy);
+        for (int k = 0; k < MAXC; k++) {
+          if (wxs[k] > 0.0f) {
+            const float wxy = wxs[k] * wy;
+            const float gz = urow[k];
+            const int iz = min((int)gz, d.sz - 2);
+            const float fz = gz - (float)iz;
+            acc[iz * PS] += wxy * (1.0f - fz) * contrib;
+            acc[(iz + 1) * PS] += wxy * fz * contrib;
           }
         }
       }
@@ -449,7 +469,7 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
       const float gx = gxs[x + k - ax.p_lo];
       const int ix = min((int)gx, d.sx - 2);
       const float bx = gx - (float)ix, axw = 1.0f - bx;
-      const float gz = clampf(Lp / sigma_r, 0.0f, ztop);
+      const float gz = clampf(div_by(Lp, sigma_r, rc_r), 0.0f, ztop);
       const int iz = min((int)gz, d.sz - 2);
       const float bz = gz - (float)iz, azw = 1.0f - bz;
       const int oy = RS, oz = PS;
@@ -478,7 +498,13 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
 constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;  // two workgroups per CU
 
 // Decide whether the tile kernel applies and size its LDS.  Returns false -> four-kernel path.
+// candidate pixels per axis of one grid column: <= 2 sigma_s + 5, exactly 2 sigma_s + 3 for integer sigma_s
+static int tile_maxc(float sigma_s) {
+  return ((2.0f * sigma_s + 5.0f <= 8.0f) || (sigma_s == floorf(sigma_s) && 2.0f * sigma_s + 3.0f <= 8.0f)) ? 8 : 14;
+}
+
 static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, TileLds* L, size_t* lds_bytes) {
+  const int maxc = tile_maxc(sigma_s);  // sigma_s <= 4: 2 * 4 + 5 <= 14
   if (getenv("TDK_BILATERAL_NO_FUSE")) return false;
   if (!(sigma_s >= 1.0f && sigma_s <= 4.0f)) return false;
   // no pixel may be clamped onto the last column / row (those columns collect far-away pixels)
@@ -494,9 +520,10 @@ static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, 
   }
   L->rs = ncx | 1;
   L->plane = (int)tdk_align_up((size_t)L->rs * ncy, 64);
-  const int lt = lw * lh, bt = d.sz * L->plane;
+  const int lt = lw * lh + (ncx + ncy) * (maxc + 1), bt = d.sz * L->plane;  // sample tile + splat tables | blur temp
   L->usize = (int)tdk_align_up((size_t)(lt > bt ? lt : bt), 64);
   L->lw = lw; L->lh = lh;
+  L->ncx = ncx; L->ncy = ncy;
   *lds_bytes = ((size_t)d.sz * L->plane + L->usize + (size_t)lw + (size_t)lh) * sizeof(float);
   return *lds_bytes <= FUSED_LDS_LIMIT;
 }
@@ -513,9 +540,7 @@ int launch_tiles(const TL* lum, const T* rgb, T* out, int width, int height, con
     TDK_LAUNCH("tdk_bilateral(tiles)", (bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), grid, dim3(FNT), lds_bytes, s, lum, rgb, out, width, height, d, \
                sigma_s, sigma_r, detail, tiles_x, ntiles, L);                                                                                     \
   } while (0)
-  // candidate pixels per axis of one grid column: <= 2 sigma_s + 5, exactly 2 sigma_s + 3 for integer sigma_s
-  const bool narrow = (2.0f * sigma_s + 5.0f <= 8.0f) || (sigma_s == floorf(sigma_s) && 2.0f * sigma_s + 3.0f <= 8.0f);
-  if (narrow) { if (vec) TDK_BT(4, 8); else TDK_BT(1, 8); }
+  if (tile_maxc(sigma_s) == 8) { if (vec) TDK_BT(4, 8); else TDK_BT(1, 8); }
   else { if (vec) TDK_BT(4, 14); else TDK_BT(1, 14); }
 #undef TDK_BT
   return TDK_OK;
