@@ -40,18 +40,17 @@ struct WParams {
   float wf[32];  // analysis (FFT) window
   float wi[32];  // synthesis (interpolation) window
   float m1[16];  // separable mask factor, index p mod s
-  float wfwi[32];  // wf[k] * wi[k]
 };
 
-// cos/sin(2 pi k / 32), k = 0..15
-__device__ constexpr float TW_COS[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
-                                         0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.19509032201612819f,
-                                         -0.38268343236508973f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254535f,
-                                         -0.92387953251128674f, -0.98078528040323043f};
-__device__ constexpr float TW_SIN[16] = {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f,
-                                         0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f,
-                                         0.92387953251128674f, 0.83146961230254546f, 0.70710678118654757f, 0.55557023301960218f,
-                                         0.38268343236508989f, 0.19509032201612861f};
+// cos/sin(2 pi k / 32), k = 0..15 (doubles: the butterflies fold tan / cot from them at compile time)
+constexpr double TW_COS_D[16] = {1.0, 0.98078528040323043, 0.92387953251128674, 0.83146961230254524, 0.70710678118654757,
+                                 0.55557023301960229, 0.38268343236508984, 0.19509032201612833, 0.0, -0.19509032201612819,
+                                 -0.38268343236508973, -0.55557023301960196, -0.70710678118654746, -0.83146961230254535,
+                                 -0.92387953251128674, -0.98078528040323043};
+constexpr double TW_SIN_D[16] = {0.0, 0.19509032201612825, 0.38268343236508978, 0.55557023301960218, 0.70710678118654746,
+                                 0.83146961230254524, 0.92387953251128674, 0.98078528040323043, 1.0, 0.98078528040323043,
+                                 0.92387953251128674, 0.83146961230254546, 0.70710678118654757, 0.55557023301960218,
+                                 0.38268343236508989, 0.19509032201612861};
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 constexpr int bitrev(int v, int bits) {
@@ -61,13 +60,15 @@ constexpr int bitrev(int v, int bits) {
 }
 
 // In-register radix-2 decimation-in-time FFT of N complex points (same butterfly network as
-// the reference's shuffle FFT, fft.h:133-167).  Forward: e^{-i...}; inverse: e^{+i...}, scaled 1/N.
+// the reference's shuffle FFT, fft.h:133-167).  Forward: e^{-i...}; inverse: e^{+i...}, UNSCALED
+// (the caller folds the 1/N of each inverse pass into the Wiener gain).
+// A general butterfly a +- w b is written with the twiddle factored as w = c (1 -+ i tan) (or
+// s (cot -+ i) when |c| < |s|): two FMAs form b (1 -+ i tan), four more give both outputs -- 6
+// instructions instead of the 4 multiplies/FMAs + 4 adds of the textbook form.
 template <int N, bool INV> __device__ __forceinline__ void fft_inreg(float (&re)[N], float (&im)[N]) {
   constexpr int STAGES = ilog2(N);
 #pragma unroll
   for (int t = 0; t < N; t++) {
-    constexpr int dummy = 0;
-    (void)dummy;
     const int r = bitrev(t, STAGES);
     if (t < r) {
       const float a = re[t], b = im[t];
@@ -83,26 +84,31 @@ template <int N, bool INV> __device__ __forceinline__ void fft_inreg(float (&re)
       if ((t & step) == 0) {
         const int p = t | step;
         const int k = (t & (step - 1)) * ((N / 2) >> s) * (32 / N);  // index into the 32-point table
-        float br, bi;
+        const float ar = re[t], ai = im[t], br = re[p], bi = im[p];
         if (k == 0) {            // w = 1
-          br = re[p]; bi = im[p];
+          re[t] = ar + br; im[t] = ai + bi;
+          re[p] = ar - br; im[p] = ai - bi;
         } else if (k == 8) {     // w = -i (forward) / +i (inverse)
-          br = INV ? -im[p] : im[p];
-          bi = INV ? re[p] : -re[p];
+          const float xr = INV ? -bi : bi, xi = INV ? br : -br;
+          re[t] = ar + xr; im[t] = ai + xi;
+          re[p] = ar - xr; im[p] = ai - xi;
         } else {
-          const float wr = TW_COS[k], wim = INV ? TW_SIN[k] : -TW_SIN[k];
-          br = re[p] * wr - im[p] * wim;
-          bi = re[p] * wim + im[p] * wr;
+          // w = c - i sg (forward), c + i sg (inverse):  w b = (br c + bi sg') + i (bi c - br sg'), sg' = -+sg
+          const double cd = TW_COS_D[k], sd = INV ? -TW_SIN_D[k] : TW_SIN_D[k];
+          if ((cd < 0 ? -cd : cd) >= (sd < 0 ? -sd : sd)) {
+            const float c = (float)cd, tn = (float)(sd / cd);
+            const float pr = __builtin_fmaf(tn, bi, br), pi = __builtin_fmaf(-tn, br, bi);   // b (1 - i tn)
+            re[t] = __builtin_fmaf(c, pr, ar); im[t] = __builtin_fmaf(c, pi, ai);
+            re[p] = __builtin_fmaf(-c, pr, ar); im[p] = __builtin_fmaf(-c, pi, ai);
+          } else {
+            const float sn = (float)sd, ct = (float)(cd / sd);
+            const float pr = __builtin_fmaf(ct, br, bi), pi = __builtin_fmaf(ct, bi, -br);    // b (ct - i)
+            re[t] = __builtin_fmaf(sn, pr, ar); im[t] = __builtin_fmaf(sn, pi, ai);
+            re[p] = __builtin_fmaf(-sn, pr, ar); im[p] = __builtin_fmaf(-sn, pi, ai);
+          }
         }
-        const float ar = re[t], ai = im[t];
-        re[t] = ar + br; im[t] = ai + bi;
-        re[p] = ar - br; im[p] = ai - bi;
       }
     }
-  }
-  if (INV) {
-#pragma unroll
-    for (int t = 0; t < N; t++) { re[t] *= (1.0f / N); im[t] *= (1.0f / N); }
   }
 }
 
@@ -152,25 +158,23 @@ __device__ __forceinline__ void load_row(const T* __restrict__ row_ptr, int ox, 
 }
 
 // dst[k] += (v[k] + mean * wf[k] wf[ty]) * (wi[k] wi[ty])  (reference denoise.cu:172-175), written as
-// (v[k] * wi[ty]) * wi[k] + (mean * wf[ty] wi[ty]) * (wf[k] wi[k]) so that every per-column factor is
-// a scalar (SGPR) operand instead of 64 per-lane registers.  16-B read-modify-writes when the
-// column offset allows.
+// wi[k] * (v[k] * wi[ty] + (mean * wf[ty] wi[ty]) * wf[k]) so that every per-column factor is a scalar
+// (SGPR) operand instead of 64 per-lane registers: 3 instructions per sample.  16-B
+// read-modify-writes when the column offset allows.
 template <int K>
 __device__ __forceinline__ void accumulate_row(float* dst, const float (&v)[K], float mean, float wy, float iy, const WParams& prm, bool vec) {
   const float mw = mean * (wy * iy);
+  auto term = [&](int k, float a) { return __builtin_fmaf(prm.wi[k], __builtin_fmaf(mw, prm.wf[k], v[k] * iy), a); };
   if (vec) {
 #pragma unroll
     for (int k = 0; k < K; k += 4) {
       float4 a = *reinterpret_cast<float4*>(dst + k);
-      a.x += (v[k] * iy) * prm.wi[k] + mw * prm.wfwi[k];
-      a.y += (v[k + 1] * iy) * prm.wi[k + 1] + mw * prm.wfwi[k + 1];
-      a.z += (v[k + 2] * iy) * prm.wi[k + 2] + mw * prm.wfwi[k + 2];
-      a.w += (v[k + 3] * iy) * prm.wi[k + 3] + mw * prm.wfwi[k + 3];
+      a.x = term(k, a.x); a.y = term(k + 1, a.y); a.z = term(k + 2, a.z); a.w = term(k + 3, a.w);
       *reinterpret_cast<float4*>(dst + k) = a;
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < K; k++) dst[k] += (v[k] * iy) * prm.wi[k] + mw * prm.wfwi[k];
+    for (int k = 0; k < K; k++) dst[k] = term(k, dst[k]);
   }
 }
 
@@ -290,10 +294,11 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
         for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
         mean_a = sa / (float)(K * K);
         mean_b = sb / (float)(K * K);
+        const float ca = -mean_a * wy, cb = -mean_b * wy;
 #pragma unroll
         for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
-          re[k] = ((re[k] - mean_a) * wy) * prm.wf[k];
-          im[k] = ((im[k] - mean_b) * wy) * prm.wf[k];
+          re[k] = __builtin_fmaf(re[k], wy, ca) * prm.wf[k];
+          im[k] = __builtin_fmaf(im[k], wy, cb) * prm.wf[k];
         }
       }
 
@@ -302,27 +307,30 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
       transpose_tile<K>(im, my_t, row);
       fft_inreg<K, false>(re, im);            // along y (lane = kx)
 
-      // separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  Index k and
-      // its mirror K-k are handled together so the partner lane still sees the untouched values.
-      auto shrink = [&](float zr, float zi, float pr, float pi, float& outr, float& outi) {
-        const float ar = 0.5f * (zr + pr), ai = 0.5f * (zi - pi);
-        const float br = 0.5f * (zi + pi), bi = -0.5f * (zr - pr);
-        const float pa = (ar * ar + ai * ai) + 1e-15f, pb = (br * br + bi * bi) + 1e-15f;
-        const float ga = fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa);
-        const float gb = fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb);
-        outr = ga * ar - gb * bi;
-        outi = ga * ai + gb * br;
-      };
+      // Separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  With
+      // 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])):  Z'[k] = ga A + i gb B and, because A
+      // and B are spectra of real tiles, Z'[-k] = ga conj(A) + i gb conj(B) -- the same gains and
+      // products.  Z[-k] lives in the partner lane (column -kx) at register -ky, and the partner
+      // needs exactly the mirrored pair, so every lane evaluates only index ky = k (k = 0..K/2 and
+      // its by-product for the partner's register K-k) and the two lanes swap by-products: half the
+      // gain arithmetic of evaluating every bin.  The 1/2 of A, B and the 1/K^2 of the two
+      // unscaled inverse passes are powers of two folded into the gain (exact).
+      constexpr float GSCALE = 0.5f / (float)(K * K);
 #pragma unroll
       for (int k = 0; k <= K / 2; k++) {
         const int k2 = (K - k) & (K - 1);
-        const float p_k2_r = __shfl(re[k2], partner, 64), p_k2_i = __shfl(im[k2], partner, 64);  // Z[-k] for index k
-        const float p_k_r = __shfl(re[k], partner, 64), p_k_i = __shfl(im[k], partner, 64);      // Z[-k2] for index k2
-        float r0, i0, r1, i1;
-        shrink(re[k], im[k], p_k2_r, p_k2_i, r0, i0);
-        shrink(re[k2], im[k2], p_k_r, p_k_i, r1, i1);
-        re[k] = r0; im[k] = i0;
-        if (k2 != k) { re[k2] = r1; im[k2] = i1; }
+        const float zr = re[k], zi = im[k];
+        const float pr = __shfl(re[k2], partner, 64), pi = __shfl(im[k2], partner, 64);  // Z[-k]
+        const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
+        const float pa = __builtin_fmaf(a2r * a2r + a2i * a2i, 0.25f, 1e-15f), pb = __builtin_fmaf(b2r * b2r + b2i * b2i, 0.25f, 1e-15f);
+        const float ga = (fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa)) * GSCALE;
+        const float gb = (fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb)) * GSCALE;
+        const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
+        re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
+        if (k2 != k) {
+          re[k2] = __shfl(gar + gbi, partner, 64);            // my Z'[K-k] is the partner's by-product
+          im[k2] = __shfl(gbr - gai, partner, 64);
+        }
       }
 
       fft_inreg<K, true>(re, im);             // inverse along y
@@ -448,7 +456,6 @@ template <int K> WParams make_params(const Geometry& g, int ov) {
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
-  for (int k = 0; k < K; k++) prm.wfwi[k] = prm.wf[k] * prm.wi[k];
   for (int r = 0; r < g.s; r++) {
     float m = 0.0f;
     for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
