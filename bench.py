@@ -182,11 +182,22 @@ def main():
     torch.cuda.synchronize()
 
     use_timer = not args.no_kernel_timer
+    # Untimed profiling pass: every launch of one step bracketed by events -> the per-kernel table
+    # and the dominant kernel.  In the timed region only THAT kernel keeps its events (measured live,
+    # on its launch stream), so the throughput number is not taxed by ~100 event pairs per step.
+    table, dom = {}, None
+    if use_timer:
+        _native.profile_enable(True)
+        step()
+        torch.cuda.synchronize()
+        table = _native.profile_report()
+        _native.profile_enable(False)
+        dom = max(table.items(), key=lambda kv: kv[1][1])[0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     if use_timer:
-        _native.profile_enable(True)
+        _native.profile_enable(True, only=dom)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -214,9 +225,9 @@ def main():
     roofline = None
     stage_ms = {}
     if report:
-        launches_total = sum(c for c, _ in report.values())
-        stage_ms = {k: round(ms / (frames * args.steps), 4) for k, (c, ms) in sorted(report.items(), key=lambda kv: -kv[1][1])}
-        dom, (cnt, ms) = max(report.items(), key=lambda kv: kv[1][1])
+        launches_total = sum(c for c, _ in table.values()) * args.steps
+        stage_ms = {k: round(ms / frames, 4) for k, (c, ms) in sorted(table.items(), key=lambda kv: -kv[1][1])}  # from the untimed pass
+        cnt, ms = report[dom]  # the dominant kernel, timed live in the timed region
         avg_s = ms / cnt / 1e3
         bpp = algorithmic_bytes_per_px(dom, sbytes)
         achieved = (bpp * w * h / avg_s / 1e9) if bpp else None
@@ -249,6 +260,7 @@ def main():
         'pipeline_roofline': {'algorithmic_bytes_per_px': pipe_bpp, 'achieved_GBps_per_gpu': round(pipe_gbs, 2), 'frac_of_8TBps': round(pipe_gbs / HBM_PEAK_GBS, 5)},
         'roofline': roofline,
         'kernel_ms_per_frame': stage_ms,
+        'kernel_ms_per_frame_source': 'one untimed step with every launch bracketed by events; the roofline kernel is timed live in the timed region',
     }
     if world == 1 and not args.no_cpu_baseline:
         try:

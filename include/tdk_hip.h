@@ -49,8 +49,11 @@ const char* tdk_last_error(void);
 /* Optional per-kernel device timing (the reference's counterpart: CudaTimer, csrc/cuda_utils.h:40-85).
  * While enabled every kernel launch is bracketed by two events on its stream.
  * tdk_profile_report blocks until they complete, writes "name launches total_ms\n" lines
- * (NUL-terminated, truncated to cap) and returns the bytes needed.  Enabling clears old records. */
+ * (NUL-terminated, truncated to cap) and returns the bytes needed.  Enabling clears old records.
+ * tdk_profile_filter restricts the timer to launches whose name contains `substr` (NULL or "" =
+ * all), so one kernel can be timed inside a throughput run without events between the others. */
 int tdk_profile_enable(int on);
+int tdk_profile_filter(const char* substr);
 int64_t tdk_profile_report(char* buf, int64_t cap);
 
 /* ---- 12-bit packed raw codec: reference csrc/packed.cu:158-280 (extension.cpp:159-169).

@@ -22,7 +22,8 @@ TDK_EXPORT int tdk_abi_version(void) { return TDK_ABI_VERSION; }
 TDK_EXPORT const char* tdk_last_error(void) { return g_last_error; }
 
 // ---------------------------------------------------------------- per-kernel event timer
-// When enabled, every TDK_LAUNCH is bracketed by two hipEvents recorded on the launch stream.
+// When enabled, every TDK_LAUNCH (or, with tdk_profile_filter, every launch whose name contains the
+// filter string) is bracketed by two hipEvents recorded on the launch stream.
 // tdk_profile_report() synchronises those events and returns, per kernel name, the launch
 // count and the summed device time.  Off by default: the launch path then costs one branch.
 bool g_tdk_profile_on = false;
@@ -35,6 +36,7 @@ struct Rec {
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
+std::string g_filter;
 
 hipEvent_t get_event() {
   if (!g_pool.empty()) {
@@ -48,11 +50,13 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-void tdk_timer_begin(const char* name, hipStream_t s) {
+bool tdk_timer_begin(const char* name, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_filter.empty() && strstr(name, g_filter.c_str()) == nullptr) return false;
   Rec r{name, get_event(), get_event()};
   if (r.a) (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
+  return true;
 }
 
 void tdk_timer_end(hipStream_t s) {
@@ -68,6 +72,14 @@ TDK_EXPORT int tdk_profile_enable(int on) {
   }
   g_recs.clear();
   g_tdk_profile_on = on != 0;
+  return TDK_OK;
+}
+
+// Restrict the timer to launches whose name contains `substr` (NULL or "" = every launch), so that
+// timing one kernel inside a throughput measurement does not put events between all the others.
+TDK_EXPORT int tdk_profile_filter(const char* substr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_filter = substr ? substr : "";
   return TDK_OK;
 }
 

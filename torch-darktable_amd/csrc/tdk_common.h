@@ -47,15 +47,15 @@ void tdk_set_error(const char* fmt, ...);
 // Every kernel launch goes through TDK_LAUNCH: optional per-kernel event timing (the
 // tdk_profile_* entry points; the reference's counterpart is its CudaTimer,
 // csrc/cuda_utils.h:40-85) plus the launch-error check.
-void tdk_timer_begin(const char* name, hipStream_t s);
+bool tdk_timer_begin(const char* name, hipStream_t s);  // false: filtered out, not recorded
 void tdk_timer_end(hipStream_t s);
 extern bool g_tdk_profile_on;
 
 #define TDK_LAUNCH(name, kernel, grid, block, lds, stream, ...)                       \
   do {                                                                                \
-    if (g_tdk_profile_on) tdk_timer_begin(name, stream);                              \
+    const bool tdk_timed_ = g_tdk_profile_on && tdk_timer_begin(name, stream);        \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                \
-    if (g_tdk_profile_on) tdk_timer_end(stream);                                      \
+    if (tdk_timed_) tdk_timer_end(stream);                                            \
     TDK_CHECK_LAUNCH(name);                                                           \
   } while (0)
 

@@ -19,6 +19,7 @@ SIGNATURES = {
   'tdk_abi_version': (c_int, []),
   'tdk_last_error': (C.c_char_p, []),
   'tdk_profile_enable': (c_int, [c_int]),
+  'tdk_profile_filter': (c_int, [C.c_char_p]),
   'tdk_profile_report': (c_int64, [C.c_char_p, c_int64]),
   'tdk_encode12_u16': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
   'tdk_encode12_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -83,8 +84,10 @@ def check(status: int) -> None:
     raise RuntimeError(lib.tdk_last_error().decode('utf-8', 'replace'))
 
 
-def profile_enable(on: bool) -> None:
-  """Switch the library's per-kernel event timer on (clearing old records) or off."""
+def profile_enable(on: bool, only: str | None = None) -> None:
+  """Switch the library's per-kernel event timer on (clearing old records) or off.  `only`
+  restricts it to kernels whose name contains that string (None: every launch)."""
+  check(lib.tdk_profile_filter(only.encode() if only else None))
   check(lib.tdk_profile_enable(int(on)))
 
 
