@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    for (int i = lane; i < K * AST; i += 64) acc[i] = 0.0f;
+    for (int i = lane; i < K * AST / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
     // the spectra are separated with the Hermitian identities A[k] = (Z[k] + conj(Z[-k])) / 2,
@@ -346,16 +346,32 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // fold the private accumulators: slab row r gets wave w's row r - w*s, for 0 <= r - w*s < K
+    // fold the private accumulators: slab row r gets wave w's row r - w*s for the (at most ov)
+    // waves with 0 <= r - w*s < K, summed in increasing w (s = K / ov is a power of two)
     float* slab = slabs + (size_t)grp * (size_t)(RSX * RSY);
-    for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
-      const int r = i / RSX, c = i - r * RSX;
-      float v = 0.0f;
-      for (int w = 0; w < NW; w++) {
-        const int rr = r - w * s;
-        if (rr >= 0 && rr < K) v += lds[w * per_wave + rr * AST + c];
+    const int ls = 31 - __clz(s);
+    if ((RSX & 3) == 0) {
+      const int QX = RSX >> 2;
+      const float inv_qx = 1.0f / (float)QX;
+      for (int i = threadIdx.x; i < QX * RSY; i += 64 * NW) {
+        const int r = (int)(((float)i + 0.5f) * inv_qx), q = i - r * QX;  // exact: i < 2^20, QX < 2^10
+        const int w_hi = min(r >> ls, NW - 1), w_lo = (r >= K) ? ((r - K) >> ls) + 1 : 0;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int w = w_lo; w <= w_hi; w++) {
+          const float4 a = *reinterpret_cast<const float4*>(lds + w * per_wave + (r - (w << ls)) * AST + 4 * q);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        reinterpret_cast<float4*>(slab)[i] = v;
       }
-      slab[i] = v;
+    } else {
+      const float inv_rsx = 1.0f / (float)RSX;
+      for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
+        const int r = (int)(((float)i + 0.5f) * inv_rsx), c = i - r * RSX;
+        const int w_hi = min(r >> ls, NW - 1), w_lo = (r >= K) ? ((r - K) >> ls) + 1 : 0;
+        float v = 0.0f;
+        for (int w = w_lo; w <= w_hi; w++) v += lds[w * per_wave + (r - (w << ls)) * AST + c];
+        slab[i] = v;
+      }
     }
     __syncthreads();  // the accumulators are zeroed again at the top of the loop
   }
