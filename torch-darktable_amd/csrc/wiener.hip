@@ -377,26 +377,30 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   }
 }
 
-// Sum the overlapping slabs of one channel, normalise by the analytic mask, crop.
+// Sum the overlapping slabs of one channel, normalise by the analytic mask, crop.  One workgroup
+// walks whole image rows (no per-pixel index division; s and BS are powers of two).
 template <typename T>
 __global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int C, int chan, int s,
                                                      int K, int jmin, int ngx, WParams prm) {
-  const int64_t n = (int64_t)W * H;
   const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
   const int u0 = -jmin * s;  // = (ov - 1) * s: pixel 0 sits at this offset inside group 0
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-    const int ux = x + u0, uy = y + u0;
-    const int gx = ux / BS, gy = uy / BSY;
-    const int offx = ux - gx * BS, offy = uy - gy * BSY;
-    const bool px = (offx < K - s) && gx > 0, py = (offy < K - s) && gy > 0;
-    auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RSX * RSY) + (size_t)oy * RSX + ox]; };
-    float v = slab_at(gx, gy, offx, offy);
-    if (px) v += slab_at(gx - 1, gy, offx + BS, offy);
-    if (py) v += slab_at(gx, gy - 1, offx, offy + BSY);
-    if (px && py) v += slab_at(gx - 1, gy - 1, offx + BS, offy + BSY);
-    const float mask = prm.m1[x % s] * prm.m1[y % s];
-    st(out, (size_t)i * C + chan, v / (mask + 1e-15f));
+  const size_t slab_sz = (size_t)RSX * RSY;
+  for (int y = blockIdx.y; y < H; y += gridDim.y) {
+    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
+    const bool py = (offy < K - s) && gy > 0;
+    const float my = prm.m1[y & (s - 1)];
+    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;                   // group row gy
+    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;  // group row gy - 1
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
+      const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
+      const bool px = (offx < K - s) && gx > 0;
+      float v = row0[gx * slab_sz + offx];
+      if (px) v += row0[(gx - 1) * slab_sz + offx + BS];
+      if (py) v += row1[gx * slab_sz + offx];
+      if (px && py) v += row1[(gx - 1) * slab_sz + offx + BS];
+      const float mask = prm.m1[x & (s - 1)] * my;
+      st(out, ((size_t)y * W + x) * C + chan, v / (mask + 1e-15f));
+    }
   }
 }
 
@@ -407,34 +411,38 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restrict__ slabs, const T* __restrict__ rgb, T* __restrict__ out, int W, int H,
                                                             int s, int K, int jmin, int ngx, WParams prm) {
 #pragma clang fp contract(off)
-  const int64_t n = (int64_t)W * H / VEC;  // VEC == 4 requires W % 4 == 0: a group never straddles a row
   const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
   const int u0 = -jmin * s;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
-    const int64_t i0 = g * VEC;
-    const int y = (int)(i0 / W), x0 = (int)(i0 - (int64_t)y * W);
+  const size_t slab_sz = (size_t)RSX * RSY;
+  const int ngroup = W / VEC;  // VEC == 4 requires W % 4 == 0: a group never straddles a row
+  for (int y = blockIdx.y; y < H; y += gridDim.y) {
     const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
     const bool py = (offy < K - s) && gy > 0;
-    const float my = prm.m1[y % s];
-    float v[3 * VEC];
-    if constexpr (VEC == 4) rgb4_io<T>::load(rgb, (size_t)g, v);
-    else { v[0] = ld(rgb, (size_t)i0 * 3); v[1] = ld(rgb, (size_t)i0 * 3 + 1); v[2] = ld(rgb, (size_t)i0 * 3 + 2); }
+    const float my = prm.m1[y & (s - 1)];
+    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;
+    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroup; g += gridDim.x * 256) {
+      const int x0 = g * VEC;
+      const size_t gi = (size_t)y * ngroup + g;
+      float v[3 * VEC];
+      if constexpr (VEC == 4) rgb4_io<T>::load(rgb, gi, v);
+      else { v[0] = ld(rgb, gi * 3); v[1] = ld(rgb, gi * 3 + 1); v[2] = ld(rgb, gi * 3 + 2); }
 #pragma unroll
-    for (int k = 0; k < VEC; k++) {
-      const int x = x0 + k;
-      const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
-      const bool px = (offx < K - s) && gx > 0;
-      auto slab_at = [&](int ggx, int ggy, int ox, int oy) { return slabs[((size_t)ggy * ngx + ggx) * (size_t)(RSX * RSY) + (size_t)oy * RSX + ox]; };
-      float acc = slab_at(gx, gy, offx, offy);
-      if (px) acc += slab_at(gx - 1, gy, offx + BS, offy);
-      if (py) acc += slab_at(gx, gy - 1, offx, offy + BSY);
-      if (px && py) acc += slab_at(gx - 1, gy - 1, offx + BS, offy + BSY);
-      const float mask = prm.m1[x % s] * my;
-      const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc / (mask + 1e-15f));
-      v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+      for (int k = 0; k < VEC; k++) {
+        const int x = x0 + k;
+        const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
+        const bool px = (offx < K - s) && gx > 0;
+        float acc = row0[gx * slab_sz + offx];
+        if (px) acc += row0[(gx - 1) * slab_sz + offx + BS];
+        if (py) acc += row1[gx * slab_sz + offx];
+        if (px && py) acc += row1[(gx - 1) * slab_sz + offx + BS];
+        const float mask = prm.m1[x & (s - 1)] * my;
+        const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc / (mask + 1e-15f));
+        v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+      }
+      if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
+      else { st(out, gi * 3, v[0]); st(out, gi * 3 + 1, v[1]); st(out, gi * 3 + 2, v[2]); }
     }
-    if constexpr (VEC == 4) rgb4_io<T>::store(out, (size_t)g, v);
-    else { st(out, (size_t)i0 * 3, v[0]); st(out, (size_t)i0 * 3 + 1, v[1]); st(out, (size_t)i0 * 3 + 2, v[2]); }
   }
 }
 
@@ -508,7 +516,7 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   for (int c = 0; c < C; c++) {
     const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
     if (rc != TDK_OK) return rc;
-    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3(stream_blocks((int64_t)W * H)), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
+    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
                K, g.jmin, g.ngx, prm);
   }
   return TDK_OK;
@@ -526,10 +534,10 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
   rc = launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
   if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16))
-    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3(stream_blocks((int64_t)W * H / 4)), dim3(256), 0, st_, slabs,
+    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3((unsigned)tdk_div_up(W / 4, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
                reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
   else
-    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 1>), dim3(stream_blocks((int64_t)W * H)), dim3(256), 0, st_, slabs,
+    TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 1>), dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
                reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
   return TDK_OK;
 }
