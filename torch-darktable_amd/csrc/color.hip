@@ -34,7 +34,7 @@ template <int OP> __device__ __forceinline__ f3 apply_op(f3 c, const OpArgs& a, 
 
 inline int stream_grid(int64_t nthreads) {
   int64_t b = tdk_div_up64(nthreads, 256);
-  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
 template <int OP> __global__ __launch_bounds__(256) void color_vec4(const float* __restrict__ in, float* __restrict__ out, int64_t ngroups, OpArgs a) {

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void tonemap_tail(const T* __restrict__ in, ui
 
 inline int stream_grid(int64_t nthreads) {
   int64_t b = tdk_div_up64(nthreads, 256);
-  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
 template <typename T, int MODE>
