@@ -61,7 +61,7 @@ def parse_args():
 # (bytes in + bytes out) with s = bytes per stored sample (2 for f16, 4 for f32).  SURVEY.md 8(d).
 def algorithmic_bytes_per_px(kernel: str, s: int) -> float | None:
     table = {
-        'tdk_rcd(interior)': 1 * s + 3 * s,          # bayer in, rgb out
+        'tdk_rcd': 1 * s + 3 * s,                    # bayer in, rgb out
         # on the fused Wiener.process_log_luminance path the op boundary is RGB in, RGB out (the
         # log-luminance planes are internal): SURVEY.md 8(d) "denoise 6 + 6 = 12 B/px" at fp16
         'tdk_wiener(tiles)': 3 * s + 3 * s,

@@ -122,6 +122,11 @@ int tdk_image_metrics_init(float* acc, tdk_stream_t stream);
 int tdk_image_metrics_accumulate(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc,
                                  int dtype, tdk_stream_t stream);
 int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream);
+/* One image, one launch: init + accumulate + finish of the three calls above.  `state` is 9 floats
+ * of device memory that must be ZERO before the first call; the kernel leaves it zero again, so it
+ * can be reused by later calls on the same stream (not concurrently from two streams). */
+int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* state,
+                      float* metrics, int dtype, tdk_stream_t stream);
 
 enum tdk_tonemap { TDK_TONEMAP_REINHARD = 0, TDK_TONEMAP_ACES = 1, TDK_TONEMAP_ACES_ADAPTIVE = 2, TDK_TONEMAP_LINEAR = 3 };
 /* reinhard_tonemap / aces_tonemap / adaptive_aces_tonemap / linear_tonemap:

@@ -220,6 +220,16 @@ def test_bounds_and_metrics(td, oracle, dev, scene):
         assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
     sat = np.ones((16, 16, 3), np.float32)
     assert np.array_equal(npy(td.compute_image_metrics([gpu(sat, dev)], 1)), np.zeros(5, np.float32))
+    # one image = the single-launch, self-cleaning path: repeated calls (also on another stream) give the same answer
+    for k in (0, 1):
+        for rescale in (False, True):
+            ref = oracle.image_metrics([imgs[k]], 2, 1e-4, rescale)
+            for _ in range(3):
+                assert np.allclose(npy(td.compute_image_metrics([ts[k]], stride=2, rescale=rescale)), ref, rtol=2e-5, atol=2e-6)
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        got = td.compute_image_metrics([ts[0].half()], stride=2)
+    torch.cuda.synchronize()
+    assert np.allclose(npy(got), oracle.image_metrics([imgs[0].astype(np.float16).astype(np.float32)], 2, 1e-4, False), rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize('name', ['reinhard', 'aces', 'adaptive_aces', 'linear'])

@@ -54,9 +54,86 @@ __device__ float stale_diff(const T* __restrict__ in, int row, int col, int w, i
   return diff_1_1(in, (int)(flat / w), (int)(flat % w), w, h, p_plane);
 }
 
+// ---------------------------------------------------------------- border ring [0, 7)
+// Intermediate image of the reference's border path at (x, y): ring < 3 -> 3x3 same-colour
+// average (ppg.cu:342-389); otherwise native sample + PPG-style green (rcd.cu:285-385).
 template <typename T>
-__global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok) {
+__device__ f3 border_temp(const T* __restrict__ in, int x, int y, int w, int h, uint32_t pattern) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return mk3(0.0f, 0.0f, 0.0f);
+  if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3)
+    return border_average([&](int xx, int yy) { return ld(in, (size_t)yy * w + xx); }, x, y, w, h, pattern);
+  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? fmaxf(0.0f, ld(in, (size_t)yy * w + xx)) : 0.0f; };
+  const int c = cfa_color(y, x, pattern);
+  f3 v = mk3(0.0f, 0.0f, 0.0f);
+  const float pc = rd(x, y);
+  if (c == 0) v.x = pc;
+  else if (c == 2) v.z = pc;
+  else v.y = pc;
+  if (c != 1) {
+    float hx[7], vy[7];
+#pragma unroll
+    for (int d = -3; d <= 3; d++) { hx[d + 3] = rd(x + d, y); vy[d + 3] = rd(x, y + d); }
+    v.y = ppg_green(hx, vy);
+  }
+  return mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
+}
+
+// Ring pixel number i: RBAND full rows (top + bottom) then CBAND columns of the middle rows.
+template <typename T>
+__device__ void border_pixel(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int64_t i) {
+  const int rband = min(h, 14), cband = min(w, 14);
+  const int mid_rows = max(h - 14, 0);
+  const int64_t n_rows = (int64_t)rband * w, n_cols = (int64_t)mid_rows * cband;
+  if (i >= n_rows + n_cols) return;
+  int x, y;
+  if (i < n_rows) {
+    const int r = (int)(i / w);
+    x = (int)(i - (int64_t)r * w);
+    y = (r < 7) ? r : h - rband + r;
+  } else {
+    const int64_t j = i - n_rows;
+    const int r = (int)(j / cband), cidx = (int)(j - (int64_t)r * cband);
+    y = 7 + r;
+    x = (cidx < 7) ? cidx : w - cband + cidx;
+  }
+  // rcd_border_redblue (rcd.cu:387-493): 3x3 neighbourhood of max(0, temp)
+  f3 nbv[3][3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+      const f3 t = border_temp(in, x + dx, y + dy, w, h, pattern);
+      nbv[dy + 1][dx + 1] = mk3(fmaxf(0.0f, t.x), fmaxf(0.0f, t.y), fmaxf(0.0f, t.z));
+    }
+  f3 col = nbv[1][1];
+  if (y > 0 && x > 0 && x < w - 1 && y < h - 1) {
+    auto nb = [&](int dx, int dy) { return nbv[dy + 1][dx + 1]; };
+    col = ppg_redblue(nb, col, cfa_color(y, x, pattern), cfa_color(y, x + 1, pattern) == 0);
+  }
+  const size_t p = (size_t)y * w + x;
+  st(out, p * 3, fmaxf(col.x, 0.0f));
+  st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
+  st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
+}
+
+// stand-alone ring kernel: images too small to have an interior
+template <typename T>
+__global__ __launch_bounds__(256) void rcd_border(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern) {
+  border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
+                                                    int tiles_x) {
   extern __shared__ float lds[];
+  // The first `nborder` workgroups do the border ring (independent of the tiles: disjoint output
+  // pixels, input read-only), so the ring costs a few workgroup slots inside this launch instead
+  // of a latency-bound launch of its own.
+  if ((int)blockIdx.x < nborder) {
+    border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * NT + threadIdx.x);
+    return;
+  }
+  const int tile = (int)blockIdx.x - nborder, tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   float* pA = lds;               // cfa
   float* pB = lds + PLANE;       // v_diff, then p_diff at odd columns and q_diff at (odd - 1)
   float* pC = lds + 2 * PLANE;   // h_diff, then step-5.1 colour at R/B sites
@@ -64,7 +141,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
   float* pE = lds + 4 * PLANE;   // R/B sites: lpf then PQ_dir; their green partner (c ^ 1): green from step 3.1
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int x0 = tile_x * TW, y0 = tile_y * TH;
   const int gx0 = x0 - HALO, gy0 = y0 - HALO;  // global coords of local (0, 0); both even
   const int rowpar0 = cfa_color(0, 0, pattern) & 1, rowpar1 = cfa_color(1, 0, pattern) & 1;
   auto rb_par = [&](int gy) { return (gy & 1) ? rowpar1 : rowpar0; };  // column parity of the R/B sites of a row
@@ -369,69 +446,6 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
   }
 }
 
-// ---------------------------------------------------------------- border ring [0, 7)
-// Intermediate image of the reference's border path at (x, y): ring < 3 -> 3x3 same-colour
-// average (ppg.cu:342-389); otherwise native sample + PPG-style green (rcd.cu:285-385).
-template <typename T>
-__device__ f3 border_temp(const T* __restrict__ in, int x, int y, int w, int h, uint32_t pattern) {
-  if (x < 0 || y < 0 || x >= w || y >= h) return mk3(0.0f, 0.0f, 0.0f);
-  if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3)
-    return border_average([&](int xx, int yy) { return ld(in, (size_t)yy * w + xx); }, x, y, w, h, pattern);
-  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? fmaxf(0.0f, ld(in, (size_t)yy * w + xx)) : 0.0f; };
-  const int c = cfa_color(y, x, pattern);
-  f3 v = mk3(0.0f, 0.0f, 0.0f);
-  const float pc = rd(x, y);
-  if (c == 0) v.x = pc;
-  else if (c == 2) v.z = pc;
-  else v.y = pc;
-  if (c != 1) {
-    float hx[7], vy[7];
-#pragma unroll
-    for (int d = -3; d <= 3; d++) { hx[d + 3] = rd(x + d, y); vy[d + 3] = rd(x, y + d); }
-    v.y = ppg_green(hx, vy);
-  }
-  return mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void rcd_border(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern) {
-  // ring pixels: RBAND full rows (top + bottom) then CBAND columns of the middle rows
-  const int rband = min(h, 14), cband = min(w, 14);
-  const int mid_rows = max(h - 14, 0);
-  const int64_t n_rows = (int64_t)rband * w, n_cols = (int64_t)mid_rows * cband;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_rows + n_cols) return;
-  int x, y;
-  if (i < n_rows) {
-    const int r = (int)(i / w);
-    x = (int)(i - (int64_t)r * w);
-    y = (r < 7) ? r : h - rband + r;
-  } else {
-    const int64_t j = i - n_rows;
-    const int r = (int)(j / cband), cidx = (int)(j - (int64_t)r * cband);
-    y = 7 + r;
-    x = (cidx < 7) ? cidx : w - cband + cidx;
-  }
-  // rcd_border_redblue (rcd.cu:387-493): 3x3 neighbourhood of max(0, temp)
-  f3 nbv[3][3];
-#pragma unroll
-  for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-    for (int dx = -1; dx <= 1; dx++) {
-      const f3 t = border_temp(in, x + dx, y + dy, w, h, pattern);
-      nbv[dy + 1][dx + 1] = mk3(fmaxf(0.0f, t.x), fmaxf(0.0f, t.y), fmaxf(0.0f, t.z));
-    }
-  f3 col = nbv[1][1];
-  if (y > 0 && x > 0 && x < w - 1 && y < h - 1) {
-    auto nb = [&](int dx, int dy) { return nbv[dy + 1][dx + 1]; };
-    col = ppg_redblue(nb, col, cfa_color(y, x, pattern), cfa_color(y, x + 1, pattern) == 0);
-  }
-  const size_t p = (size_t)y * w + x;
-  st(out, p * 3, fmaxf(col.x, 0.0f));
-  st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
-  st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
-}
-
 template <typename T>
 int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
   const T* in = reinterpret_cast<const T*>(bayer);
@@ -441,12 +455,15 @@ int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStre
   // per launch (cheap, and correct whichever device is current)
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                "tdk_rcd(hipFuncSetAttribute)");
-  if (w > 14 && h > 14) {
-    TDK_LAUNCH("tdk_rcd(interior)", rcd_interior<T>, dim3(tdk_div_up(w, TW), tdk_div_up(h, TH)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok);
-  }
   const int rband = h < 14 ? h : 14, cband = w < 14 ? w : 14;
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
-  TDK_LAUNCH("tdk_rcd(border)", rcd_border<T>, dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
+  if (w > 14 && h > 14) {
+    const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
+    TDK_LAUNCH("tdk_rcd", rcd_interior<T>, dim3((unsigned)(nborder + tiles_x * tiles_y)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok, nborder,
+               tiles_x);
+  } else {
+    TDK_LAUNCH("tdk_rcd(border)", rcd_border<T>, dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
+  }
   return TDK_OK;
 }
 

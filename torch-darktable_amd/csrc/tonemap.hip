@@ -76,9 +76,13 @@ __global__ void metrics_init_kernel(float* acc) {
   if (threadIdx.x < 8) acc[threadIdx.x] = 0.0f;
 }
 
-template <typename T>
+// FUSED: the last workgroup to finish (ticket counter at acc[8]) normalises the sums into
+// `metrics` and zeroes acc[0..8] again, so one launch replaces init + accumulate + finish and the
+// state buffer is ready for the next call.
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
-                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc) {
+                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc,
+                                                      float* __restrict__ metrics) {
   __shared__ float part[4][6];
   const int64_t n = (int64_t)sw * sh;
   const float b0 = bounds[0];
@@ -105,7 +109,31 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
     if ((threadIdx.x & 63) == 0) part[wave][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 6) atomicAdd(&acc[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+  const float mine = (threadIdx.x < 6) ? (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]) : 0.0f;
+  if constexpr (!FUSED) {
+    if (threadIdx.x < 6) atomicAdd(&acc[threadIdx.x], mine);
+  } else {
+    // No device-scope fence here: on gfx950 a release fence at agent scope writes the XCD's L2 back
+    // (measured: 3x the whole kernel).  Device-scope atomics are performed at the coherence point;
+    // a RETURNING atomic has been performed once its value is back, so "sums, wait, ticket" in
+    // program order of one wave is enough.
+    __shared__ unsigned int ticket;
+    if (threadIdx.x < 6) {
+      const float old = __hip_atomic_fetch_add(&acc[threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));  // keep the returning form
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(acc + 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket == gridDim.x - 1) {  // every other workgroup has added its sums
+      float v = 0.0f;
+      if (threadIdx.x < 6) v = __hip_atomic_exchange(&acc[threadIdx.x], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read and reset
+      const float cnt = __shfl(v, 5, 64);
+      if (threadIdx.x < 5) metrics[threadIdx.x] = v * (1.0f / fmaxf(cnt, 1.0f));  // color_adaption.cu:161-165
+      if (threadIdx.x == 0) __hip_atomic_exchange(reinterpret_cast<unsigned int*>(acc + 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // color_adaption.cu:161-165
@@ -211,6 +239,12 @@ inline int stream_grid(int64_t nthreads) {
   return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
+// reductions that end in same-address atomics: at most one workgroup per CU
+inline int reduce_grid(int64_t nthreads) {
+  int64_t b = tdk_div_up64(nthreads, 256);
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
 template <typename T, int MODE>
 int run_tonemap(const void* rgb, uint8_t* out, int64_t npix, const float* metrics, float gamma, float intensity, float light_adapt,
                 float vibrance, hipStream_t s) {
@@ -253,7 +287,7 @@ TDK_EXPORT int tdk_image_bounds_accumulate(const void* rgb, int width, int heigh
   TDK_REQUIRE(rgb && bounds, "tdk_image_bounds_accumulate: null pointer");
   TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_bounds_accumulate: invalid size/stride");
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
-  const int grid = stream_grid((int64_t)sw * sh);
+  const int grid = reduce_grid((int64_t)sw * sh);
   TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_bounds_accumulate", bounds_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
                                                   reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, bounds));
   return TDK_OK;
@@ -270,9 +304,21 @@ TDK_EXPORT int tdk_image_metrics_accumulate(const void* rgb, int width, int heig
   TDK_REQUIRE(rgb && bounds && acc, "tdk_image_metrics_accumulate: null pointer");
   TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics_accumulate: invalid size/stride");
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
-  const int grid = stream_grid((int64_t)sw * sh);
-  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", metrics_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
-                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc));
+  const int grid = reduce_grid((int64_t)sw * sh);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", (metrics_kernel<T, false>), dim3(grid), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc,
+                                                  static_cast<float*>(nullptr)));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* state,
+                                 float* metrics, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb && bounds && state && metrics, "tdk_image_metrics: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics: invalid size/stride");
+  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
+  const int grid = reduce_grid((int64_t)sw * sh);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics", (metrics_kernel<T, true>), dim3(grid), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, state, metrics));
   return TDK_OK;
 }
 

@@ -42,6 +42,7 @@ SIGNATURES = {
   'tdk_image_metrics_init': (c_int, [c_void_p, c_void_p]),
   'tdk_image_metrics_accumulate': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
   'tdk_image_metrics_finish': (c_int, [c_void_p, c_void_p, c_void_p]),
+  'tdk_image_metrics': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
   'tdk_tonemap': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'tdk_wiener_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
   'tdk_wiener': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -431,14 +431,39 @@ def compute_image_bounds(images: Sequence[torch.Tensor], stride: int = 8) -> tor
   return bounds
 
 
+_UNIT_BOUNDS: dict = {}
+_METRICS_STATE: dict = {}
+
+
+def _unit_bounds(dev: torch.device) -> torch.Tensor:
+  """Device-resident [0, 1] (no per-call host-to-device copy)."""
+  key = (dev.type, dev.index)
+  if key not in _UNIT_BOUNDS:
+    _UNIT_BOUNDS[key] = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
+  return _UNIT_BOUNDS[key]
+
+
+def _metrics_state(dev: torch.device) -> torch.Tensor:
+  """Zero-initialised, self-cleaning state of tdk_image_metrics: one per (device, stream)."""
+  key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  if key not in _METRICS_STATE:
+    _METRICS_STATE[key] = torch.zeros(16, dtype=torch.float32, device=dev)
+  return _METRICS_STATE[key]
+
+
 def compute_image_metrics(images: Sequence[torch.Tensor], stride: int = 8, min_gray: float = 1e-4, rescale: bool = False) -> torch.Tensor:
   _require(len(images) > 0, 'images must be non-empty')
   dev = images[0].device
   _require(dev.type == 'cuda', 'image must be CUDA')
-  bounds = compute_image_bounds(images, stride) if rescale else torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
-  acc = torch.empty(8, dtype=torch.float32, device=dev)
+  bounds = compute_image_bounds(images, stride) if rescale else _unit_bounds(dev)
   metrics = torch.empty(5, dtype=torch.float32, device=dev)
   with torch.cuda.device(dev):
+    if len(images) == 1:  # the per-frame case: one self-cleaning launch instead of init + accumulate + finish
+      x = images[0].contiguous()
+      check(lib.tdk_image_metrics(_ptr(x), x.size(1), x.size(0), int(stride), float(min_gray), _ptr(bounds), _ptr(_metrics_state(dev)),
+                                  _ptr(metrics), _dtype_tag(x), _stream()))
+      return metrics
+    acc = torch.empty(8, dtype=torch.float32, device=dev)
     check(lib.tdk_image_metrics_init(_ptr(acc), _stream()))
     for img in images:
       x = img.contiguous()
