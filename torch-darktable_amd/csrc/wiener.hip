@@ -199,7 +199,7 @@ __host__ __device__ inline int acc_stride(int n) {
 template <typename T, int K>
 __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan,
                                                         int s, int ov, int jmin, int ntile_x, int ntile_y, int ngx, int ngroups,
-                                                        const float* __restrict__ sigmas, WParams prm) {
+                                                        const float* __restrict__ sigmas, WParams prm, int nplanes, size_t plane_stride) {
   constexpr int TPW = 64 / K;  // tile pairs (slots) per wave
   extern __shared__ __align__(16) float lds[];
   const int GTX = TPW * ov;
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   float* tbuf = acc + K * AST;         // per-wave transpose scratch
   const int row = lane & (K - 1), slot = lane / K;
   float* my_t = tbuf + slot * (K * (K + 1));
-  const float sigma = sigmas[chan];
-  const float sig2 = sigma * sigma;
+  // nplanes > 1: `img` holds that many separate planes (C == 1 each, plane_stride samples apart), group
+  // index = plane * ngroups + group, noise sigma = sigmas[chan + plane]
+  const int total_groups = ngroups * nplanes;
   const int partner = (lane & ~(K - 1)) | ((K - row) & (K - 1));  // lane holding column -kx of the same slot
   const float wy = prm.wf[row], iy = prm.wi[row];
   const int nsteps = ov >> 1;
@@ -226,18 +227,19 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
     bool act_a, act_b;
     const T* src_row;
   };
-  auto make_item = [&](int grp, int base) {
+  auto make_item = [&](int grp_all, int base) {
     Item it;
+    const int plane = grp_all / ngroups, grp = grp_all - plane * ngroups;
     const int gx = grp % ngx, gy = grp / ngx;
     const int jx0 = jmin + gx * GTX, jy = jmin + gy * NW + wave;
-    const bool row_active = (grp < ngroups) && (jy < jmin + ntile_y);
+    const bool row_active = (grp_all < total_groups) && (jy < jmin + ntile_y);
     it.txa = slot * ov + 2 * base;
     it.txb = it.txa + 1;
     it.act_a = row_active && (jx0 + it.txa < jmin + ntile_x);
     it.act_b = row_active && (jx0 + it.txb < jmin + ntile_x);
     it.oxa = (jx0 + it.txa) * s;
     it.oxb = (jx0 + it.txb) * s;
-    it.src_row = img + (size_t)reflect_index(jy * s + row, H) * W * C;
+    it.src_row = img + (size_t)plane * plane_stride + (size_t)reflect_index(jy * s + row, H) * W * C;
     return it;
   };
   auto fetch = [&](const Item& it, float (&ra)[K], float (&rb)[K]) {
@@ -262,7 +264,9 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   Item cur = make_item((int)blockIdx.x, 0);
   if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int grp = blockIdx.x; grp < total_groups; grp += gridDim.x) {
+    const float sigma = sigmas[chan + grp / ngroups];
+    const float sig2 = sigma * sigma;
     for (int i = lane; i < K * AST / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
@@ -446,6 +450,65 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
   }
 }
 
+// Multi-channel input: de-interleave HWC into fp32 planes once, so that the tile kernel reads
+// contiguous rows with 16-B loads (a strided channel read costs one cache line per sample).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void split_planes3(const T* __restrict__ rgb, float* __restrict__ planes, int64_t npix) {
+  const int64_t ng = npix / VEC;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ng; g += (int64_t)gridDim.x * 256) {
+    float v[3 * VEC];
+    if constexpr (VEC == 4) rgb4_io<T>::load(rgb, (size_t)g, v);
+    else { v[0] = ld(rgb, (size_t)g * 3); v[1] = ld(rgb, (size_t)g * 3 + 1); v[2] = ld(rgb, (size_t)g * 3 + 2); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float o[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; k++) o[k] = v[3 * k + c];
+      if constexpr (VEC == 4) s4_io<float>::store(planes + (size_t)c * npix, (size_t)g, o);
+      else planes[(size_t)c * npix + g] = o[0];
+    }
+  }
+}
+
+// Finish for three planes at once: fold the slabs of each channel, normalise, write interleaved RGB.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int s, int K, int jmin, int ngx,
+                                                      int ngroups, WParams prm) {
+  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
+  const int u0 = -jmin * s;
+  const size_t slab_sz = (size_t)RSX * RSY, chan_sz = slab_sz * ngroups;
+  const int ngroup = W / VEC;
+  for (int y = blockIdx.y; y < H; y += gridDim.y) {
+    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
+    const bool py = (offy < K - s) && gy > 0;
+    const float my = prm.m1[y & (s - 1)];
+    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;
+    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroup; g += gridDim.x * 256) {
+      const size_t gi = (size_t)y * ngroup + g;
+      float v[3 * VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const int x = g * VEC + k;
+        const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
+        const bool px = (offx < K - s) && gx > 0;
+        const float norm = prm.m1[x & (s - 1)] * my + 1e-15f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float* r0 = row0 + c * chan_sz;
+          float acc = r0[gx * slab_sz + offx];
+          if (px) acc += r0[(gx - 1) * slab_sz + offx + BS];
+          if (py) acc += row1[c * chan_sz + gx * slab_sz + offx];
+          if (px && py) acc += row1[c * chan_sz + (gx - 1) * slab_sz + offx + BS];
+          v[3 * k + c] = acc / norm;
+        }
+      }
+      if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
+      else { st(out, gi * 3, v[0]); st(out, gi * 3 + 1, v[1]); st(out, gi * 3 + 2, v[2]); }
+    }
+  }
+}
+
 void make_window(int K, double weight, float* w) {
   const double half = K / 2.0, scale = weight * half * half;
   double v[32], nrm = 0.0;
@@ -489,7 +552,8 @@ template <int K> WParams make_params(const Geometry& g, int ov) {
 }
 
 template <typename T, int K>
-int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, const float* sigmas, const Geometry& g, const WParams& prm, hipStream_t st_) {
+int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, const float* sigmas, const Geometry& g, const WParams& prm, hipStream_t st_,
+                 int nplanes = 1) {
   constexpr int TPW = 64 / K;
   const size_t lds_bytes = (size_t)NW * ((size_t)K * acc_stride(g.RSX) + TPW * K * (K + 1)) * sizeof(float);
   TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
@@ -497,9 +561,9 @@ int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, 
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int ngroups = g.ngx * g.ngy;
-  const int blocks = ngroups < cus ? ngroups : cus;  // persistent: one workgroup per CU (LDS-limited), grid-stride over the groups
+  const int blocks = ngroups * nplanes < cus ? ngroups * nplanes : cus;  // persistent: one workgroup per CU (LDS-limited), grid-stride over the groups
   TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(blocks), dim3(64 * NW), lds_bytes, st_, in, slabs, W, H, C, c, g.s, ov, g.jmin, g.ntx,
-             g.nty, g.ngx, ngroups, sigmas, prm);
+             g.nty, g.ngx, ngroups, sigmas, prm, nplanes, (size_t)W * H);
   return TDK_OK;
 }
 
@@ -513,6 +577,22 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   const Geometry g = geometry(W, H, K, ov);
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
+  if (C == 3) {
+    // de-interleave -> one tile launch over 3 x groups -> one finish that writes whole RGB pixels
+    const size_t slab_floats = (size_t)g.ngx * g.ngy * g.RSX * g.RSY;
+    float* planes = slabs + tdk_align_up(3 * slab_floats, 64);
+    const int64_t npix = (int64_t)W * H;
+    const bool vec = (W % 4) == 0 && tdk_aligned(in, 16) && tdk_aligned(out, 16);
+    const T* tin = reinterpret_cast<const T*>(in);
+    if (vec) TDK_LAUNCH("tdk_wiener(split)", (split_planes3<T, 4>), dim3(stream_blocks(npix / 4)), dim3(256), 0, st_, tin, planes, npix);
+    else TDK_LAUNCH("tdk_wiener(split)", (split_planes3<T, 1>), dim3(stream_blocks(npix)), dim3(256), 0, st_, tin, planes, npix);
+    const int rc = launch_tiles<float, K>(planes, slabs, W, H, 1, 0, ov, sigmas, g, prm, st_, 3);
+    if (rc != TDK_OK) return rc;
+    const dim3 fgrid((unsigned)tdk_div_up(vec ? W / 4 : W, 256), (unsigned)(H < 32768 ? H : 32768));
+    if (vec) TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 4>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g.s, K, g.jmin, g.ngx, g.ngx * g.ngy, prm);
+    else TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 1>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g.s, K, g.jmin, g.ngx, g.ngx * g.ngy, prm);
+    return TDK_OK;
+  }
   for (int c = 0; c < C; c++) {
     const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
     if (rc != TDK_OK) return rc;
@@ -546,9 +626,11 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 
 TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
-  (void)channels;  // channels are processed one after another through the same slabs
   const Geometry g = geometry(width, height, tile_size, overlap_factor);
-  return tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY * sizeof(float), 256);
+  const size_t slab_floats = (size_t)g.ngx * g.ngy * g.RSX * g.RSY;
+  if (channels == 3)  // one slab set per channel + the three de-interleaved fp32 planes
+    return tdk_align_up((tdk_align_up(3 * slab_floats, 64) + 3 * (size_t)width * height) * sizeof(float), 256);
+  return tdk_align_up(slab_floats * sizeof(float), 256);
 }
 
 TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
