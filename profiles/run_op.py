@@ -1,7 +1,7 @@
 """Run one op of the hot path a few times on synthetic 12 MP data -- the target of the
 rocprofv3 passes whose summaries are committed in this directory.
 
-  python profiles/run_op.py {rcd,wiener,bilateral,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
+  python profiles/run_op.py {rcd,ppg,postprocess,wiener,bilateral,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
 """
 import argparse
 import sys
@@ -31,6 +31,9 @@ def main():
     bayer = synthetic_bayer(h, w, 1234, dev).to(dt)
     rcd = td.RCD(dev, (w, h), td.BayerPattern.RGGB)
     rgb = rcd.process(bayer)
+    ppg = td.PPG(dev, (w, h), td.BayerPattern.RGGB)
+    rgb32 = rgb.float()
+    post = td.PostProcess(dev, (w, h), td.BayerPattern.RGGB, color_smoothing_passes=3, green_eq_local=True, green_eq_global=False)
     lum = td.compute_luminance(rgb)
     loglum = td.compute_log_luminance(rgb, 1e-4)
     wiener = td.Wiener(dev, (w, h), 4, 32)
@@ -41,6 +44,10 @@ def main():
     for _ in range(a.iters):
         if a.op == 'rcd':
             rcd.process(bayer)
+        elif a.op == 'ppg':
+            ppg.process(bayer)
+        elif a.op == 'postprocess':
+            post.process(rgb32)
         elif a.op == 'wiener':
             wiener.process(loglum.unsqueeze(2), 0.075)
         elif a.op == 'bilateral':

@@ -20,23 +20,19 @@
 
 namespace {
 
-__device__ __forceinline__ void cswap(float& a, float& b) {
-  const float x = a;
-  const bool c = a > b;
-  a = c ? b : a;
-  b = c ? x : b;
-}
-
-// reference csrc/reduction.h:93-116
+// Median of nine (reference csrc/reduction.h:93-116 uses a 19-exchange sorting network).  The
+// median is a VALUE, not an order of operations, so any exact selection gives the same bits:
+// with lo/mid/hi = min3/med3/max3 of each row of three,
+//   median9 = med3(max3(lo0, lo1, lo2), med3(mid0, mid1, mid2), min3(hi0, hi1, hi2))
+// -- 12 three-input VALU instructions instead of 57 compare/selects.
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ float median9(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float s8) {
-  cswap(s1, s2); cswap(s4, s5); cswap(s7, s8);
-  cswap(s0, s1); cswap(s3, s4); cswap(s6, s7);
-  cswap(s1, s2); cswap(s4, s5); cswap(s7, s8);
-  cswap(s0, s3); cswap(s5, s8); cswap(s4, s7);
-  cswap(s3, s6); cswap(s1, s4); cswap(s2, s5);
-  cswap(s4, s7); cswap(s4, s2); cswap(s6, s4);
-  cswap(s4, s2);
-  return s4;
+  const float lo = max3f(min3f(s0, s1, s2), min3f(s3, s4, s5), min3f(s6, s7, s8));
+  const float mid = med3f(med3f(s0, s1, s2), med3f(s3, s4, s5), med3f(s6, s7, s8));
+  const float hi = min3f(max3f(s0, s1, s2), max3f(s3, s4, s5), max3f(s6, s7, s8));
+  return med3f(lo, mid, hi);
 }
 
 constexpr int STW = 64, STH = 16, SLW = STW + 2, SLH = STH + 2, SLS = SLW + 1;

@@ -33,49 +33,70 @@ __global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, cons
   __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
 
-  for (int i = threadIdx.x; i < RW_ * RHT; i += 256) {
-    const int r = i / RW_, c = i - r * RW_;
-    const int gx = x0 - RH + c, gy = y0 - RH + r;
-    raw[r * RS + c] = (gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld(src, (size_t)gy * width + gx) : 0.0f;
+  {
+    // all global loads of the thread are issued before the first LDS store (a load -> store loop
+    // would expose one memory latency per iteration)
+    constexpr int NLD = (RW_ * RHT + 255) / 256;
+    float tmp[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i / RW_, c = i - r * RW_;
+      const int gx = x0 - RH + c, gy = y0 - RH + r;
+      tmp[k] = (i < RW_ * RHT && gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld(src, (size_t)gy * width + gx) : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i / RW_, c = i - r * RW_;
+      if (i < RW_ * RHT) raw[r * RS + c] = tmp[k];
+    }
   }
   __syncthreads();
 
-  for (int i = threadIdx.x; i < GW * GH; i += 256) {
-    const int r = i / GW, c = i - r * GW;
-    const int gx = x0 - 1 + c, gy = y0 - 1 + r;
-    f3 v = mk3(0.0f, 0.0f, 0.0f);
-    if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
-      if (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3) {
-        v = border_average([&](int xx, int yy) { return ld(orig, (size_t)yy * width + xx); }, gx, gy, width, height, pattern);
-      } else {
-        const float* ctr = raw + (r + RH - 1) * RS + (c + RH - 1);
-        const int cc = cfa_color(gy, gx, pattern);
-        const float pc = ctr[0];
-        if (cc == 0) v.x = pc;
-        else if (cc == 2) v.z = pc;
-        else v.y = pc;
-        if (cc != 1) {
-          float h[7], vv[7];
+  // The 66 x 34 region is walked one CFA site class (row parity, column parity) at a time, so every
+  // lane of a wave sits on the same kind of site: the green interpolation at red/blue sites runs
+  // with all lanes active instead of under a checkerboard mask, and green sites only copy.
+  constexpr int CW = GW / 2, CH = GH / 2;  // 33 x 17 sites per class
+  for (int cls = 0; cls < 4; cls++) {
+    const int rp = cls >> 1, cp = cls & 1;
+    for (int i = threadIdx.x; i < CW * CH; i += 256) {
+      const int rr = i / CW, r = 2 * rr + rp, c = 2 * (i - rr * CW) + cp;
+      const int gx = x0 - 1 + c, gy = y0 - 1 + r;
+      f3 v = mk3(0.0f, 0.0f, 0.0f);
+      if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
+        if (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3) {
+          v = border_average([&](int xx, int yy) { return ld(orig, (size_t)yy * width + xx); }, gx, gy, width, height, pattern);
+        } else {
+          const float* ctr = raw + (r + RH - 1) * RS + (c + RH - 1);
+          const int cc = cfa_color(gy, gx, pattern);  // the same for every lane (x0, y0 are even)
+          const float pc = ctr[0];
+          if (cc == 0) v.x = pc;
+          else if (cc == 2) v.z = pc;
+          else v.y = pc;
+          if (cc != 1) {
+            float h[7], vv[7];
 #pragma unroll
-          for (int d = -3; d <= 3; d++) {
-            h[d + 3] = ctr[d];
-            vv[d + 3] = ctr[d * RS];
+            for (int d = -3; d <= 3; d++) {
+              h[d + 3] = ctr[d];
+              vv[d + 3] = ctr[d * RS];
+            }
+            v.y = ppg_green(h, vv);
           }
-          v.y = ppg_green(h, vv);
+          v = mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
         }
-        v = mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
       }
+      pr[r * GS + c] = v.x;
+      pg[r * GS + c] = v.y;
+      pb[r * GS + c] = v.z;
     }
-    pr[r * GS + c] = v.x;
-    pg[r * GS + c] = v.y;
-    pb[r * GS + c] = v.z;
   }
   __syncthreads();
 
   const int lx = (threadIdx.x & 15) * 4;
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
-    const int ly = (threadIdx.x >> 4) + pass * 16;
+    const int ly = 2 * (threadIdx.x >> 4) + pass;  // one row parity per pass: pixel k of every lane is the same site class
     const int x = x0 + lx, y = y0 + ly;
     if (x >= width || y >= height) continue;
     float px[12];
