@@ -36,6 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / 'torch-darktable_amd'))
 sys.path.insert(0, str(ROOT))
 
+VALU_CUS, VALU_CLOCK_GHZ = 256, 2.4  # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
@@ -231,15 +232,23 @@ def main():
         avg_s = ms / cnt / 1e3
         bpp = algorithmic_bytes_per_px(dom, sbytes)
         achieved = (bpp * w * h / avg_s / 1e9) if bpp else None
-        traffic = None
+        traffic, valu = None, None
         tfile = ROOT / 'profiles' / 'traffic.json'  # written by profiles/collect_traffic.py from rocprofv3 --pmc passes
         if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get(dom)
+            tj = json.loads(tfile.read_text())
+            traffic = tj.get(dom)
+            insts = tj.get('_valu', {}).get(dom)  # SQ_INSTS_VALU: wave-instructions per launch (PMC pass of the same build)
+            if insts:
+                # a SIMD issues one wave64 VALU instruction per 4 cycles: peak = CUs * 4 SIMDs * clock / 4
+                peak_ginst = VALU_CUS * 4 * VALU_CLOCK_GHZ / 4
+                valu = {'wave_insts_per_launch': insts, 'achieved_Ginst_per_s': round(insts / avg_s / 1e9, 1), 'peak_Ginst_per_s': round(peak_ginst, 1),
+                        'issue_frac': round(insts / avg_s / 1e9 / peak_ginst, 4),
+                        'note': 'the kernel is FP32-vector bound; bytes/s against HBM is reported above because the contract asks for it'}
         roofline = {
             'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None, 'traffic': traffic,
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches': cnt, 'algorithmic_bytes_per_launch': int(bpp * w * h) if bpp else None,
-            'kernel_launches_in_timed_region': launches_total,
+            'kernel_launches_in_timed_region': launches_total, 'valu': valu,
         }
     # whole-pipeline roofline at the Python-wrapper stage boundaries (41 B/px f16, 79 B/px f32; RCD only: 4*s B/px)
     pipe_bpp = (41 if storage == 'f16' else 79) if args.workload == 'isp' else 4 * sbytes

@@ -1,11 +1,13 @@
-"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950)
-into profiles/traffic.json: HBM-side bytes per launch for each library kernel.
+"""Turns rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950 -- and
+optionally SQ_INSTS_VALU) into profiles/traffic.json: HBM-side bytes per launch for each library
+kernel, plus its vector-ALU instruction count (wave-instructions per launch) under "_valu".
 
 On the GPU box:
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/profiles/run_op.py isp --iters 3
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/profiles/run_op.py isp --iters 3
-  python3 $REPO/profiles/collect_traffic.py $OUT/fetch $OUT/write $REPO/gpurun_out/traffic.json
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/valu -- python3 $REPO/profiles/run_op.py isp --iters 3
+  python3 $REPO/profiles/collect_traffic.py $OUT/fetch $OUT/write $REPO/gpurun_out/traffic.json [$OUT/valu]
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB-like units of
 1024 B... the counters derive from TCC_EA0_RDREQ x 64 B, and on gfx950 a wide coalesced streaming
@@ -24,8 +26,10 @@ KERNELS = {
     'wiener_tiles': ('tdk_wiener(tiles)', True),
     'wiener_finish_modify': ('tdk_wiener(finish+modify)', False),
     'wiener_finish<': ('tdk_wiener(finish)', False),
-    'rcd_interior': ('tdk_rcd(interior)', False),
+    'rcd_interior': ('tdk_rcd', False),
     'rcd_border': ('tdk_rcd(border)', False),
+    'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
+    'metrics_kernel': ('tdk_image_metrics', False),
     'splat_gather_kernel': ('tdk_bilateral(splat)', False),
     'blur_xy_kernel': ('tdk_bilateral(blur_xy)', False),
     'blur_z_kernel': ('tdk_bilateral(blur_z)', False),
@@ -54,6 +58,7 @@ def mean_counter(directory, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    valu = mean_counter(sys.argv[4], 'SQ_INSTS_VALU') if len(sys.argv) > 4 else {}
     fetch = mean_counter(fetch_dir, 'FETCH_SIZE')
     write = mean_counter(write_dir, 'WRITE_SIZE')
     result, detail = {}, {}
@@ -65,7 +70,8 @@ def main():
         result[name] = int(rd + wr)
         detail[name] = {'FETCH_SIZE_raw': fetch.get(frag), 'WRITE_SIZE_raw': write.get(frag), 'read_bytes': int(rd), 'write_bytes': int(wr),
                         'read_doubled': wide}
-    json.dump({**result, '_detail': detail, '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'},
+    valu_named = {KERNELS[k][0]: int(v) for k, v in valu.items()}
+    json.dump({**result, '_valu': valu_named, '_detail': detail, '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'},
               open(out, 'w'), indent=1)
     print(json.dumps(result, indent=1))
 
