@@ -9,6 +9,8 @@ with the source tree; no JIT cache, no torch headers.
 from __future__ import annotations
 
 import argparse
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -19,6 +21,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 OBJ = HERE / 'build'
 LIB = HERE / 'torch_darktable' / 'libtdk_hip.so'
+STAMP = HERE / 'torch_darktable' / 'libtdk_hip.so.sha256'  # hash of the sources + flags the library was built from
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
@@ -30,6 +33,41 @@ CXXFLAGS = ['-O3', '-std=c++17', f'--offload-arch={ARCH}', '-ffp-contract=off', 
 
 
 CXXFLAGS += os.environ.get('TDK_EXTRA_FLAGS', '').split()  # experiments: e.g. TDK_EXTRA_FLAGS=-DTDK_WIENER_SHARED_ACC=1
+
+
+def _inputs():
+  return sorted(CSRC.glob('*.hip')) + sorted(CSRC.glob('*.h')) + [HERE.parent / 'include' / 'tdk_hip.h']
+
+
+def source_hash() -> str:
+  h = hashlib.sha256(' '.join(CXXFLAGS).encode())
+  for f in _inputs():
+    h.update(f.name.encode())
+    h.update(f.read_bytes())
+  return h.hexdigest()
+
+
+def is_current() -> bool:
+  """True when the in-tree library was built from exactly these sources and flags.  Content hash,
+  not mtimes: a copied tree (the GPU box gets a snapshot) keeps no trustworthy timestamps."""
+  return LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == source_hash()
+
+
+def ensure_current(verbose: bool = False) -> Path:
+  """Build only if the library does not match the sources.  Safe to call from several processes
+  at once (one rank per GPU): an exclusive file lock serialises the builders and the losers find
+  the finished library when they get the lock."""
+  if is_current():
+    return LIB
+  OBJ.mkdir(exist_ok=True)
+  with open(OBJ / '.lock', 'w') as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+      if not is_current():
+        build(force=True, verbose=verbose)  # object mtimes cannot be trusted either
+    finally:
+      fcntl.flock(lock, fcntl.LOCK_UN)
+  return LIB
 
 
 def _stale(target: Path, deps) -> bool:
@@ -64,10 +102,13 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
         if verbose:
           print(f'  compiled {name}')
   if todo or force or _stale(LIB, objs):
-    cmd = [HIPCC, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB), *map(str, objs)]
+    tmp = LIB.with_suffix(f'.so.tmp{os.getpid()}')
+    cmd = [HIPCC, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(tmp), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
       raise RuntimeError(f'link failed:\n{r.stderr}')
+    os.replace(tmp, LIB)  # atomic: a process that is loading the old library keeps its mapping
+  STAMP.write_text(source_hash() + '\n')
   return LIB
 
 
