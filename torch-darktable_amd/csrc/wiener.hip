@@ -319,16 +319,20 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
       // its by-product for the partner's register K-k) and the two lanes swap by-products: half the
       // gain arithmetic of evaluating every bin.  The 1/2 of A, B and the 1/K^2 of the two
       // unscaled inverse passes are powers of two folded into the gain (exact).
+      // gain = max(|A|^2 + eps - sigma^2, 0) / (|A|^2 + eps) = max(1 - sigma^2 / p, 0) with p = |A|^2 + eps and
+      // |A|^2 = |2A|^2 / 4: evaluated on p4 = |2A|^2 + 4 eps as max(GS - (4 sigma^2 GS) / p4, 0), GS = the folded
+      // 1/2 * 1/K^2 -- two FMAs for p4, then rcp + FMA + max.
       constexpr float GSCALE = 0.5f / (float)(K * K);
+      const float sgs = -4.0f * sig2 * GSCALE;
 #pragma unroll
       for (int k = 0; k <= K / 2; k++) {
         const int k2 = (K - k) & (K - 1);
         const float zr = re[k], zi = im[k];
         const float pr = __shfl(re[k2], partner, 64), pi = __shfl(im[k2], partner, 64);  // Z[-k]
         const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
-        const float pa = __builtin_fmaf(a2r * a2r + a2i * a2i, 0.25f, 1e-15f), pb = __builtin_fmaf(b2r * b2r + b2i * b2i, 0.25f, 1e-15f);
-        const float ga = (fmaxf(pa - sig2, 0.0f) * __builtin_amdgcn_rcpf(pa)) * GSCALE;
-        const float gb = (fmaxf(pb - sig2, 0.0f) * __builtin_amdgcn_rcpf(pb)) * GSCALE;
+        const float pa4 = __builtin_fmaf(a2i, a2i, __builtin_fmaf(a2r, a2r, 4e-15f)), pb4 = __builtin_fmaf(b2i, b2i, __builtin_fmaf(b2r, b2r, 4e-15f));
+        const float ga = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
+        const float gb = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
         const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
         re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
         if (k2 != k) {
