@@ -96,7 +96,7 @@ def main():
             ms = sum(v[1] for v in rep.values()) / a.iters
             rows.append({'op': name, 'ms': round(ms, 4), 'kernels_per_call': sum(v[0] for v in rep.values()) // a.iters,
                          'algorithmic_MB': round(nbytes / 1e6, 1), 'GBps': round(nbytes / ms / 1e6, 1), 'frac_of_8TBps': round(nbytes / ms / 1e6 / 8000, 4),
-                         'MPps': round(n / ms / 1e3, 0)})
+                         'MPps': round(n / ms / 1e3, 0), 'kernels': {k: round(v[1] / a.iters, 4) for k, v in rep.items()}})
         except Exception as e:  # noqa: BLE001
             rows.append({'op': name, 'error': str(e)[:200]})
         print(json.dumps(rows[-1]), flush=True)

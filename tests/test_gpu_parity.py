@@ -134,6 +134,7 @@ def test_rcd_rejects_odd_width_and_wrong_shape(td, dev):
 
 
 @pytest.mark.parametrize('cfg', [dict(color_smoothing_passes=1), dict(color_smoothing_passes=3), dict(green_eq_local=True),
+                                 dict(color_smoothing_passes=4), dict(color_smoothing_passes=6), dict(color_smoothing_passes=9, green_eq_local=True),
                                  dict(color_smoothing_passes=2, green_eq_local=True, green_eq_threshold=4.0), dict()])
 def test_postprocess_bit_exact_paths(td, oracle, dev, scene, cfg):
     h, w = 90, 134

@@ -5,10 +5,9 @@
 // (apply_white_balance).
 //
 // MI355X design
-//  * colour smoothing: 64 x 16 tile per 256-thread workgroup; the (R-G, B-G) differences of the
-//    tile + 1-px halo are staged once in two LDS planes (zero outside the image, as the
-//    reference's halo fill), the 19-compare-swap median network runs in registers, each thread
-//    emits 4 pixels as three 16-B stores.
+//  * colour smoothing: 64 x 32 tile per 512-thread workgroup; up to four passes run in one launch on
+//    (R-G, B-G) planes in LDS (zero outside the image, as the reference's halo fill), the median
+//    of nine is 12 min3/med3/max3 instructions, each thread emits 4 pixels as three 16-B stores.
 //  * global green equilibration: the reference reduces per block, sums the partials with a
 //    torch op and reads two scalars back to the host (postprocess.cu:362-366).  Here a fixed
 //    grid of workgroups writes partial sums, a single-workgroup kernel folds them in a fixed
@@ -35,35 +34,75 @@ __device__ __forceinline__ float median9(float s0, float s1, float s2, float s3,
   return med3f(lo, mid, hi);
 }
 
-constexpr int STW = 64, STH = 16, SLW = STW + 2, SLH = STH + 2, SLS = SLW + 1;
+constexpr int STW = 64, STH = 32, SNT = STH * 16;  // tile and threads per workgroup (4 pixels per thread)
 
-// postprocess.cu:24-78
-__global__ __launch_bounds__(256) void smoothing_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height, int vec_ok) {
-  __shared__ float dr[SLH * SLS], db[SLH * SLS];
+// Up to FMAXP smoothing passes in ONE kernel: the tile + P-px halo is read once, the (R-G, B-G)
+// planes ping-pong in LDS while the valid region shrinks by one pixel per pass, and only the last
+// pass touches HBM again -- 24 B/px of traffic instead of 24 B/px per pass.  Every pass computes
+// exactly one reference pass (postprocess.cu:24-78; differences are zero outside the image at every pass).
+constexpr int FMAXP = 4;
+constexpr int FLW = STW + 2 * FMAXP, FLH = STH + 2 * FMAXP, FLS = FLW + 1;
+
+__global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height, int vec_ok,
+                                                              int passes) {
+  __shared__ float G[FLH * FLS], DR[2][FLH * FLS], DB[2][FLH * FLS];
+  const int P = passes;  // 1..FMAXP
   const int x0 = blockIdx.x * STW, y0 = blockIdx.y * STH;
-  for (int i = threadIdx.x; i < SLW * SLH; i += 256) {
-    const int r = i / SLW, c = i - r * SLW;
-    const int gx = x0 - 1 + c, gy = y0 - 1 + r;
-    float a = 0.0f, b = 0.0f;
+  const int rw = STW + 2 * P, rh = STH + 2 * P;
+  // i / n by float reciprocal: exact for i < 2^20, n < 2^10 ((i + 0.5) / n is >= 0.5 / n from an integer)
+  const float inv_rw = 1.0f / (float)rw;
+  for (int i = threadIdx.x; i < rw * rh; i += SNT) {
+    const int r = (int)(((float)i + 0.5f) * inv_rw), c = i - r * rw;
+    const int gx = x0 - P + c, gy = y0 - P + r;
+    float g = 0.0f, a = 0.0f, b = 0.0f;
     if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
       const float* p = in + ((size_t)gy * width + gx) * 3;
-      a = p[0] - p[1];
-      b = p[2] - p[1];
+      g = p[1];
+      a = p[0] - g;
+      b = p[2] - g;
     }
-    dr[r * SLS + c] = a;
-    db[r * SLS + c] = b;
+    const int q = r * FLS + c;
+    G[q] = g;
+    DR[0][q] = a; DB[0][q] = b;
+    DR[1][q] = 0.0f; DB[1][q] = 0.0f;  // out-of-image sites stay zero in both buffers
   }
   __syncthreads();
+  int cur = 0;
+  for (int p = 0; p + 1 < P; p++) {
+    const int m = P - 1 - p;  // halo still needed after this pass
+    const int cw = STW + 2 * m, ch = STH + 2 * m, off = P - m;
+    const float* dr = DR[cur];
+    const float* db = DB[cur];
+    const float inv_cw = 1.0f / (float)cw;
+    for (int i = threadIdx.x; i < cw * ch; i += SNT) {
+      const int rr = (int)(((float)i + 0.5f) * inv_cw), r = rr + off, c = i - rr * cw + off;
+      const int gx = x0 - P + c, gy = y0 - P + r;
+      if (gx < 0 || gy < 0 || gx >= width || gy >= height) continue;
+      const int q = r * FLS + c;
+      const float rm = median9(dr[q - FLS - 1], dr[q - FLS], dr[q - FLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + FLS - 1], dr[q + FLS], dr[q + FLS + 1]);
+      const float bm = median9(db[q - FLS - 1], db[q - FLS], db[q - FLS + 1], db[q - 1], db[q], db[q + 1], db[q + FLS - 1], db[q + FLS], db[q + FLS + 1]);
+      const float g = G[q];
+      const float nr = fmaxf(fmaxf(rm + g, 0.0f), 0.0f), ng = fmaxf(g, 0.0f), nb = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
+      G[q] = ng;  // only this thread reads G[q]
+      DR[cur ^ 1][q] = nr - ng;
+      DB[cur ^ 1][q] = nb - ng;
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // last pass: 4 pixels per thread straight to HBM
+  const float* dr = DR[cur];
+  const float* db = DB[cur];
   const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
   const int x = x0 + lx, y = y0 + ly;
   if (x >= width || y >= height) return;
   float px[12];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int q = (ly + 1) * SLS + (lx + k + 1);
-    const float rm = median9(dr[q - SLS - 1], dr[q - SLS], dr[q - SLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + SLS - 1], dr[q + SLS], dr[q + SLS + 1]);
-    const float bm = median9(db[q - SLS - 1], db[q - SLS], db[q - SLS + 1], db[q - 1], db[q], db[q + 1], db[q + SLS - 1], db[q + SLS], db[q + SLS + 1]);
-    const float g = (x + k < width) ? in[((size_t)y * width + x + k) * 3 + 1] : 0.0f;
+    const int q = (ly + P) * FLS + (lx + k + P);
+    const float rm = median9(dr[q - FLS - 1], dr[q - FLS], dr[q - FLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + FLS - 1], dr[q + FLS], dr[q + FLS + 1]);
+    const float bm = median9(db[q - FLS - 1], db[q - FLS], db[q - FLS + 1], db[q - 1], db[q], db[q + 1], db[q + FLS - 1], db[q + FLS], db[q + FLS + 1]);
+    const float g = G[q];
     px[3 * k] = fmaxf(fmaxf(rm + g, 0.0f), 0.0f);
     px[3 * k + 1] = fmaxf(g, 0.0f);
     px[3 * k + 2] = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
@@ -79,16 +118,14 @@ __global__ __launch_bounds__(256) void green_sums_kernel(const float* __restrict
                                                          float2* __restrict__ partial) {
   __shared__ float s1[4], s2[4];
   const int we = 2 * (width / 2), he = 2 * (height / 2);
-  const int64_t n = (int64_t)we * he;
   float a = 0.0f, b = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int y = (int)(i / we), x = (int)(i - (int64_t)y * we);
-    if (cfa_color(y, x, pattern) == 1) {
-      const float g = in[((size_t)y * width + x) * 3 + 1];
-      if (y & 1) b += g;
-      else a += g;
-    }
-  }
+  for (int y = blockIdx.x; y < he; y += gridDim.x)  // whole rows per workgroup: no index division
+    for (int x = threadIdx.x; x < we; x += 256)
+      if (cfa_color(y, x, pattern) == 1) {
+        const float g = in[((size_t)y * width + x) * 3 + 1];
+        if (y & 1) b += g;
+        else a += g;
+      }
   a = wave_sum(a);
   b = wave_sum(b);
   const int wave = threadIdx.x >> 6;
@@ -115,63 +152,83 @@ __global__ __launch_bounds__(256) void green_ratio_kernel(const float2* __restri
   }
 }
 
+// Streaming kernels below: grid = (x chunks, rows), one thread per VEC consecutive pixels of a row
+// (VEC == 4: 48-B vector accesses; requires width % 4 == 0 and 16-B aligned images).
+
 // postprocess.cu:234-255
+template <int VEC>
 __global__ __launch_bounds__(256) void green_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
                                                           uint32_t pattern, const float* __restrict__ ratio) {
   const float r = ratio[0];
-  const int64_t n = (int64_t)width * height;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int y = (int)(i / width), x = (int)(i - (int64_t)y * width);
-    const bool g1 = (cfa_color(y, x, pattern) == 1) && !(y & 1);
-    const float* p = in + i * 3;
-    float* o = out + i * 3;
-    const float g = p[1] * (g1 ? r : 1.0f);
-    o[0] = fmaxf(p[0], 0.0f);
-    o[1] = fmaxf(g, 0.0f);
-    o[2] = fmaxf(p[2], 0.0f);
-  }
+  const int ngroup = width / VEC;
+  for (int y = blockIdx.y; y < height; y += gridDim.y)
+    for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroup; gi += gridDim.x * 256) {
+      const size_t g4 = (size_t)y * ngroup + gi;
+      float v[3 * VEC];
+      if constexpr (VEC == 4) rgb4_io<float>::load(in, g4, v);
+      else { v[0] = in[g4 * 3]; v[1] = in[g4 * 3 + 1]; v[2] = in[g4 * 3 + 2]; }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const bool g1 = (cfa_color(y, gi * VEC + k, pattern) == 1) && !(y & 1);
+        const float g = v[3 * k + 1] * (g1 ? r : 1.0f);
+        v[3 * k] = fmaxf(v[3 * k], 0.0f);
+        v[3 * k + 1] = fmaxf(g, 0.0f);
+        v[3 * k + 2] = fmaxf(v[3 * k + 2], 0.0f);
+      }
+      if constexpr (VEC == 4) rgb4_io<float>::store(out, g4, v);
+      else { out[g4 * 3] = v[0]; out[g4 * 3 + 1] = v[1]; out[g4 * 3 + 2] = v[2]; }
+    }
 }
 
 // postprocess.cu:84-169; threshold already divided by 100
+template <int VEC>
 __global__ __launch_bounds__(256) void green_local_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
                                                           uint32_t pattern, float threshold) {
-  const int64_t n = (int64_t)width * height;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int y = (int)(i / width), x = (int)(i - (int64_t)y * width);
-    const float* p = in + i * 3;
-    float o = p[1];
-    if (cfa_color(y, x, pattern) == 1 && (y & 1)) {
-      auto g0 = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < width && yy < height) ? in[((size_t)yy * width + xx) * 3 + 1] : 0.0f; };
-      const float maximum = 1.0f;
-      const float o1_1 = g0(x - 1, y - 1), o1_2 = g0(x + 1, y - 1), o1_3 = g0(x - 1, y + 1), o1_4 = g0(x + 1, y + 1);
-      const float o2_1 = g0(x, y - 2), o2_2 = g0(x, y + 2), o2_3 = g0(x - 2, y), o2_4 = g0(x + 2, y);
-      const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
-      const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
-      if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
-        const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4) + fabsf(o1_2 - o1_4)) / 6.0f;
-        const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4) + fabsf(o2_2 - o2_4)) / 6.0f;
-        if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
+  const int ngroup = width / VEC;
+  for (int y = blockIdx.y; y < height; y += gridDim.y)
+    for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroup; gi += gridDim.x * 256) {
+      const size_t g4 = (size_t)y * ngroup + gi;
+      float v[3 * VEC];
+      if constexpr (VEC == 4) rgb4_io<float>::load(in, g4, v);
+      else { v[0] = in[g4 * 3]; v[1] = in[g4 * 3 + 1]; v[2] = in[g4 * 3 + 2]; }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const int x = gi * VEC + k;
+        float o = v[3 * k + 1];
+        if (cfa_color(y, x, pattern) == 1 && (y & 1)) {
+          auto g0 = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < width && yy < height) ? in[((size_t)yy * width + xx) * 3 + 1] : 0.0f; };
+          const float maximum = 1.0f;
+          const float o1_1 = g0(x - 1, y - 1), o1_2 = g0(x + 1, y - 1), o1_3 = g0(x - 1, y + 1), o1_4 = g0(x + 1, y + 1);
+          const float o2_1 = g0(x, y - 2), o2_2 = g0(x, y + 2), o2_3 = g0(x - 2, y), o2_4 = g0(x + 2, y);
+          const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
+          const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
+          if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
+            const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4) + fabsf(o1_2 - o1_4)) / 6.0f;
+            const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4) + fabsf(o2_2 - o2_4)) / 6.0f;
+            if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
+          }
+        }
+        v[3 * k + 1] = fmaxf(o, 0.0f);
       }
+      if constexpr (VEC == 4) rgb4_io<float>::store(out, g4, v);
+      else { out[g4 * 3] = v[0]; out[g4 * 3 + 1] = v[1]; out[g4 * 3 + 2] = v[2]; }
     }
-    float* d = out + i * 3;
-    d[0] = p[0];
-    d[1] = fmaxf(o, 0.0f);
-    d[2] = p[2];
-  }
 }
 
 // white_balance.cu:10-42
 __global__ __launch_bounds__(256) void white_balance_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ gains,
                                                             int width, int height, uint32_t pattern) {
   const float gr = gains[0], gg = gains[1], gb = gains[2];
-  const int64_t n = (int64_t)width * height;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int y = (int)(i / width), x = (int)(i - (int64_t)y * width);
-    const int c = cfa_color(y, x, pattern);
-    const float g = (c == 0) ? gr : (c == 2 ? gb : gg);
-    out[i] = clampf(in[i] * g, 0.0f, 1.0f);
-  }
+  for (int y = blockIdx.y; y < height; y += gridDim.y)
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < width; x += gridDim.x * 256) {
+      const int c = cfa_color(y, x, pattern);
+      const float g = (c == 0) ? gr : (c == 2 ? gb : gg);
+      const size_t i = (size_t)y * width + x;
+      out[i] = clampf(in[i] * g, 0.0f, 1.0f);
+    }
 }
+
+inline dim3 row_grid(int threads_per_row, int rows) { return dim3((unsigned)tdk_div_up(threads_per_row, 256), (unsigned)(rows < 32768 ? rows : 32768)); }
 
 inline int stream_grid(int64_t nthreads) {
   int64_t b = tdk_div_up64(nthreads, 256);
@@ -182,7 +239,8 @@ inline int stream_grid(int64_t nthreads) {
 
 TDK_EXPORT size_t tdk_postprocess_workspace_bytes(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global) {
   if (width <= 0 || height <= 0) return 0;
-  const int stages = (color_smoothing_passes > 0 ? color_smoothing_passes : 0) + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);
+  const int passes = color_smoothing_passes > 0 ? color_smoothing_passes : 0;
+  const int stages = (passes + FMAXP - 1) / FMAXP + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);  // <= FMAXP passes per launch
   size_t bytes = 256 + GEQ_BLOCKS * sizeof(float2);  // ratio + partial sums
   if (stages >= 2) bytes += tdk_align_up((size_t)width * height * 3 * sizeof(float), 256);
   return tdk_align_up(bytes, 256);
@@ -196,7 +254,7 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
   TDK_REQUIRE(width > 0 && height > 0, "tdk_postprocess: invalid size %dx%d", width, height);
   hipStream_t s = tdk_stream(stream);
   const int passes = color_smoothing_passes > 0 ? color_smoothing_passes : 0;
-  const int stages = passes + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);
+  const int stages = (passes + FMAXP - 1) / FMAXP + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);
   const size_t img_bytes = (size_t)width * height * 3 * sizeof(float);
   if (stages == 0) {
     TDK_HIP_CALL(hipMemcpyAsync(rgb_out, rgb_in, img_bytes, hipMemcpyDeviceToDevice, s), "tdk_postprocess(copy)");
@@ -208,14 +266,17 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
   float* scratch = reinterpret_cast<float*>(ws + 256 + GEQ_BLOCKS * sizeof(float2));
   const int64_t npix = (int64_t)width * height;
   const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb_out, 16) && tdk_aligned(scratch, 16);
+  const bool vec_io = vec_ok && tdk_aligned(rgb_in, 16);  // kernels that also READ with 16-B accesses
 
   const float* src = rgb_in;
   int stage = 0;
   auto dst_of = [&](int i) { return ((stages - 1 - i) % 2 == 0) ? rgb_out : scratch; };
 
-  for (int p = 0; p < passes; p++, stage++) {
+  for (int left = passes; left > 0; left -= FMAXP, stage++) {
     float* dst = dst_of(stage);
-    TDK_LAUNCH("tdk_postprocess(color_smoothing)", smoothing_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(256), 0, s, src, dst, width, height, vec_ok);
+    const int n = left < FMAXP ? left : FMAXP;
+    TDK_LAUNCH("tdk_postprocess(color_smoothing)", smoothing_fused_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(SNT), 0, s, src, dst, width,
+               height, vec_ok, n);
     src = dst;
   }
   if (green_eq_global) {
@@ -223,14 +284,16 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
     const int nb = (int)(tdk_div_up64(npix, 256) < GEQ_BLOCKS ? tdk_div_up64(npix, 256) : GEQ_BLOCKS);
     TDK_LAUNCH("tdk_postprocess(green_sums)", green_sums_kernel, dim3(nb), dim3(256), 0, s, src, width, height, pattern, partial);
     TDK_LAUNCH("tdk_postprocess(green_ratio)", green_ratio_kernel, dim3(1), dim3(256), 0, s, partial, nb, ratio);
-    TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
+    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel<4>, row_grid(width / 4, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
+    else TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel<1>, row_grid(width, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
     src = dst;
   }
   if (green_eq_local) {
     float* dst = dst_of(stage++);
     // postprocess.cu:383: threshold / 100. is evaluated in double and narrowed
-    TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, src, dst, width, height, pattern,
-                       (float)((double)green_eq_threshold / 100.0));
+    const float thr = (float)((double)green_eq_threshold / 100.0);
+    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<4>, row_grid(width / 4, height), dim3(256), 0, s, src, dst, width, height, pattern, thr);
+    else TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<1>, row_grid(width, height), dim3(256), 0, s, src, dst, width, height, pattern, thr);
     src = dst;
   }
   return TDK_OK;
@@ -241,7 +304,7 @@ TDK_EXPORT int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, 
   TDK_REQUIRE(bayer_in && bayer_out && gains, "tdk_apply_white_balance: null pointer");
   TDK_REQUIRE(width > 0 && height > 0, "tdk_apply_white_balance: invalid size %dx%d", width, height);
   const int64_t npix = (int64_t)width * height;
-  TDK_LAUNCH("tdk_apply_white_balance", white_balance_kernel, dim3(stream_grid(npix)), dim3(256), 0, tdk_stream(stream), bayer_in, bayer_out, gains, width,
+  TDK_LAUNCH("tdk_apply_white_balance", white_balance_kernel, row_grid(width, height), dim3(256), 0, tdk_stream(stream), bayer_in, bayer_out, gains, width,
                      height, pattern);
   return TDK_OK;
 }
