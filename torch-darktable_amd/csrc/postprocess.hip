@@ -5,7 +5,7 @@
 // (apply_white_balance).
 //
 // MI355X design
-//  * colour smoothing: 64 x 32 tile per 512-thread workgroup; up to four passes run in one launch on
+//  * colour smoothing: 64 x 16 tile per 512-thread workgroup; up to four passes run in one launch on
 //    (R-G, B-G) planes in LDS (zero outside the image, as the reference's halo fill), the median
 //    of nine is 12 min3/med3/max3 instructions, each thread emits 4 pixels as three 16-B stores.
 //  * global green equilibration: the reference reduces per block, sums the partials with a
@@ -34,7 +34,8 @@ __device__ __forceinline__ float median9(float s0, float s1, float s2, float s3,
   return med3f(lo, mid, hi);
 }
 
-constexpr int STW = 64, STH = 32, SNT = STH * 16;  // tile and threads per workgroup (4 pixels per thread)
+constexpr int STW = 64, STH = 16, SNT = 512;  // tile and threads per workgroup: 35 KB of LDS -> 4 workgroups x 8 waves per CU
+constexpr int SPX = STW * STH / SNT;         // pixels per thread in the last pass (2)
 
 // Up to FMAXP smoothing passes in ONE kernel: the tile + P-px halo is read once, the (R-G, B-G)
 // planes ping-pong in LDS while the valid region shrinks by one pixel per pass, and only the last
@@ -90,15 +91,16 @@ __global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __res
     cur ^= 1;
     __syncthreads();
   }
-  // last pass: 4 pixels per thread straight to HBM
+  // last pass: SPX consecutive pixels per thread straight to HBM
   const float* dr = DR[cur];
   const float* db = DB[cur];
-  const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
+  constexpr int TPR = STW / SPX;  // threads per tile row
+  const int lx = (threadIdx.x % TPR) * SPX, ly = threadIdx.x / TPR;
   const int x = x0 + lx, y = y0 + ly;
   if (x >= width || y >= height) return;
-  float px[12];
+  float px[3 * SPX];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < SPX; k++) {
     const int q = (ly + P) * FLS + (lx + k + P);
     const float rm = median9(dr[q - FLS - 1], dr[q - FLS], dr[q - FLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + FLS - 1], dr[q + FLS], dr[q + FLS + 1]);
     const float bm = median9(db[q - FLS - 1], db[q - FLS], db[q - FLS + 1], db[q - 1], db[q], db[q + 1], db[q + FLS - 1], db[q + FLS], db[q + FLS + 1]);
@@ -107,7 +109,14 @@ __global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __res
     px[3 * k + 1] = fmaxf(g, 0.0f);
     px[3 * k + 2] = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
   }
-  store_rgb4(out, x, y, width, vec_ok, px);
+  float* o = out + ((size_t)y * width + x) * 3;
+  if (vec_ok) {  // width % 4 == 0, 16-B aligned image: a pixel pair starts on an 8-B boundary
+    static_assert(SPX == 2, "vector store below writes 2 pixels");
+    float2* o2 = reinterpret_cast<float2*>(o);
+    o2[0] = make_float2(px[0], px[1]); o2[1] = make_float2(px[2], px[3]); o2[2] = make_float2(px[4], px[5]);
+  } else {
+    for (int k = 0; k < SPX && x + k < width; k++) { o[3 * k] = px[3 * k]; o[3 * k + 1] = px[3 * k + 1]; o[3 * k + 2] = px[3 * k + 2]; }
+  }
 }
 
 // ---- global green equilibration

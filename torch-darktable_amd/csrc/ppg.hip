@@ -4,7 +4,7 @@
 // pre_median, ppg_demosaic_green, ppg_demosaic_redblue -- 3-4 launches, a zero-filled output
 // and a persistent float3 temp image).
 //
-// MI355X design: ONE fused kernel.  A 256-thread workgroup owns a 64 x 32 output tile:
+// MI355X design: ONE fused kernel.  A 512-thread workgroup owns a 64 x 32 output tile:
 //   1. raw CFA tile + 4-px halo -> LDS (zero outside the image), coalesced row reads;
 //   2. the reference's intermediate "green + sparse R/B" image is produced only for the
 //      66 x 34 region the tile needs, straight into three LDS planes (3-px image ring from
@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int TW = 64, TH = 32;
+constexpr int PNT = 512;                    // threads per workgroup: 4 workgroups x 8 waves per CU (LDS 39 KB each)
 constexpr int RH = 4;                       // raw halo: 1 (red/blue) + 3 (green)
 constexpr int RW_ = TW + 2 * RH, RHT = TH + 2 * RH;   // 72 x 40
 constexpr int RS = RW_ + 1;                 // padded LDS row stride
@@ -27,7 +28,7 @@ constexpr int GW = TW + 2, GH = TH + 2;     // 66 x 34 intermediate region
 constexpr int GS = GW + 1;
 
 template <typename T>
-__global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width,
+__global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width,
                                                  int height, uint32_t pattern, int vec_ok) {
   __shared__ float raw[RHT * RS];
   __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
@@ -36,18 +37,18 @@ __global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, cons
   {
     // all global loads of the thread are issued before the first LDS store (a load -> store loop
     // would expose one memory latency per iteration)
-    constexpr int NLD = (RW_ * RHT + 255) / 256;
+    constexpr int NLD = (RW_ * RHT + PNT - 1) / PNT;
     float tmp[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + k * 256;
+      const int i = threadIdx.x + k * PNT;
       const int r = i / RW_, c = i - r * RW_;
       const int gx = x0 - RH + c, gy = y0 - RH + r;
       tmp[k] = (i < RW_ * RHT && gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld(src, (size_t)gy * width + gx) : 0.0f;
     }
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + k * 256;
+      const int i = threadIdx.x + k * PNT;
       const int r = i / RW_, c = i - r * RW_;
       if (i < RW_ * RHT) raw[r * RS + c] = tmp[k];
     }
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, cons
   constexpr int CW = GW / 2, CH = GH / 2;  // 33 x 17 sites per class
   for (int cls = 0; cls < 4; cls++) {
     const int rp = cls >> 1, cp = cls & 1;
-    for (int i = threadIdx.x; i < CW * CH; i += 256) {
+    for (int i = threadIdx.x; i < CW * CH; i += PNT) {
       const int rr = i / CW, r = 2 * rr + rp, c = 2 * (i - rr * CW) + cp;
       const int gx = x0 - 1 + c, gy = y0 - 1 + r;
       f3 v = mk3(0.0f, 0.0f, 0.0f);
@@ -94,11 +95,11 @@ __global__ __launch_bounds__(256) void ppg_fused(const T* __restrict__ src, cons
   __syncthreads();
 
   const int lx = (threadIdx.x & 15) * 4;
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int ly = 2 * (threadIdx.x >> 4) + pass;  // one row parity per pass: pixel k of every lane is the same site class
+  {
+    // waves 0-3 take the even rows, waves 4-7 the odd rows: pixel k of every lane of a wave is the same site class
+    const int ly = 2 * ((threadIdx.x >> 4) & 15) + (threadIdx.x >> 8);
     const int x = x0 + lx, y = y0 + ly;
-    if (x >= width || y >= height) continue;
+    if (x >= width || y >= height) return;
     float px[12];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -167,7 +168,7 @@ int launch(const void* bayer, void* rgb, void* workspace, int width, int height,
     src = med;
   }
   const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb, 16);
-  TDK_LAUNCH("tdk_ppg", ppg_fused<T>, dim3(tdk_div_up(width, TW), tdk_div_up(height, TH)), dim3(256), 0, s, src, in, reinterpret_cast<T*>(rgb),
+  TDK_LAUNCH("tdk_ppg", ppg_fused<T>, dim3(tdk_div_up(width, TW), tdk_div_up(height, TH)), dim3(PNT), 0, s, src, in, reinterpret_cast<T*>(rgb),
                      width, height, pattern, vec_ok);
   return TDK_OK;
 }
