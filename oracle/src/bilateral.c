@@ -50,6 +50,18 @@ static inline gsample make_sample(int x, int y, float L, const int size[3], floa
 /* one line of the 5-tap blur; stride in floats (bilateral.cu:132-168) */
 static void blur_line(const float* ib, float* ob, int n, ptrdiff_t st) {
   const float w0 = 6.0f / 16.0f, w1 = 4.0f / 16.0f, w2 = 1.0f / 16.0f;
+  if (n < 4) {
+    /* The reference's line walker reads and writes past a line shorter than 4 cells (undefined
+     * behaviour; reachable only for images a few pixels wide with an aspect ratio >= 4, where
+     * compute_grid_size yields 3 cells).  Defined here -- and in the HIP kernels -- as the same
+     * stencil with zero extension, which is what the literal code computes for every n >= 4. */
+    for (int i = 0; i < n; i++) {
+      const float m2 = i >= 2 ? ib[(i - 2) * st] : 0.0f, m1 = i >= 1 ? ib[(i - 1) * st] : 0.0f;
+      const float p1 = i + 1 < n ? ib[(i + 1) * st] : 0.0f, p2 = i + 2 < n ? ib[(i + 2) * st] : 0.0f;
+      ob[i * st] = ib[i * st] * w0 + w1 * (p1 + m1) + w2 * (p2 + m2);
+    }
+    return;
+  }
   ptrdiff_t i0 = 0;
   float tmp1 = ib[i0];
   ob[i0] = ib[i0] * w0 + w1 * ib[i0 + st] + w2 * ib[i0 + 2 * st];

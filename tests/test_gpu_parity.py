@@ -306,6 +306,29 @@ def test_wiener(td, oracle, dev, scene, K, ov, C):
     assert np.abs(ident - img).max() < 2e-6
 
 
+@pytest.mark.parametrize('size', [(32, 32), (33, 40), (40, 32)])
+def test_wiener_smallest_images(td, oracle, dev, scene, size):
+    """Images barely larger than one tile: every tile is an edge tile (reflect loads on all sides)."""
+    h, w = size
+    img = scene(h, w, 51)
+    ws = td.Wiener(dev, (w, h), overlap_factor=4, tile_size=32)
+    sig = np.array([0.05, 0.08, 0.03], np.float32)
+    assert np.abs(npy(ws.process(gpu(img, dev), gpu(sig, dev))) - oracle.wiener(img, sig, 32, 4)).max() < 2e-5
+    l1 = img[:, :, :1].copy()
+    assert np.abs(npy(ws.process(gpu(l1, dev), gpu(sig[:1], dev))) - oracle.wiener(l1, sig[:1], 32, 4)).max() < 2e-5
+    with pytest.raises(RuntimeError):
+        td.Wiener(dev, (31, 40), overlap_factor=4, tile_size=32).process(gpu(scene(40, 31, 1), dev), gpu(sig, dev))
+
+
+@pytest.mark.parametrize('size', [(5, 7), (9, 13), (16, 4), (3, 64)])
+@pytest.mark.parametrize('sig', [(2.0, 0.2), (1.0, 0.1), (8.0, 0.1)])
+def test_bilateral_tiny_images(td, oracle, dev, scene, size, sig):
+    h, w = size
+    lum = oracle.compute_luminance(scene(h, w, 52))
+    ws = td.Bilateral(dev, (w, h), sigma_s=sig[0], sigma_r=sig[1])
+    assert np.array_equal(npy(ws.process(gpu(lum, dev), 0.5)), oracle.bilateral(lum, sig[0], sig[1], 0.5))
+
+
 def test_wiener_log_luminance_pipeline(td, oracle, dev, scene):
     h, w = 96, 128
     img = scene(h, w, 27)
