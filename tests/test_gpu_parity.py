@@ -110,6 +110,35 @@ def test_rcd_bit_exact(td, oracle, dev, scene, pattern, size):
     assert bad.size == 0, f'{len(bad)} mismatches, first at {bad[:5].tolist()}, max |d| {np.abs(got - ref).max()}'
 
 
+@pytest.mark.parametrize('size', [(2, 2), (2, 4), (4, 4), (4, 6), (6, 8), (10, 14), (14, 16), (16, 16), (7, 5), (3, 64), (64, 2)])
+def test_tiny_images_every_stencil_op(td, oracle, dev, size):
+    """Images smaller than every halo / tile / ring: all pixels are border cases (the oracle was run
+    under AddressSanitizer on the same sizes).  Bit-exact ops stay bit-exact."""
+    h, w = size
+    rng = np.random.default_rng(h * 100 + w)
+    bayer = rng.random((h, w, 1), dtype=np.float32)
+    for name in PATTERNS:
+        pat, opat = td.BayerPattern[name], oracle.PATTERNS[name]
+        assert np.array_equal(npy(td.bilinear5x5_demosaic(gpu(bayer, dev), pat)), oracle.bilinear5x5(bayer, opat))
+        for med in (0.0, 2.0):
+            assert np.array_equal(npy(td.PPG(dev, (w, h), pat, median_threshold=med).process(gpu(bayer, dev))), oracle.ppg(bayer, opat, med))
+        if w % 2 == 0:
+            assert np.array_equal(npy(td.RCD(dev, (w, h), pat).process(gpu(bayer, dev))), oracle.rcd(bayer, opat))
+    rgb = rng.random((h, w, 3), dtype=np.float32)
+    cfg = dict(color_smoothing_passes=5, green_eq_local=True)
+    assert np.array_equal(npy(td.PostProcess(dev, (w, h), td.BayerPattern.RGGB, **cfg).process(gpu(rgb, dev))),
+                          oracle.postprocess(rgb, oracle.RGGB, **cfg))
+    gains = np.array([1.7, 1.0, 1.4], np.float32)
+    assert np.array_equal(npy(td.apply_white_balance(gpu(bayer[:, :, 0], dev), gpu(gains, dev), td.BayerPattern.GRBG)),
+                          oracle.apply_white_balance(bayer[:, :, 0], gains, oracle.GRBG))
+    lum = oracle.compute_luminance(rgb)
+    assert np.abs(npy(td.compute_luminance(gpu(rgb, dev))) - lum).max() < 2e-5
+    m = oracle.image_metrics([rgb], 2)
+    assert np.allclose(npy(td.compute_image_metrics([gpu(rgb, dev)], stride=2)), m, rtol=2e-5, atol=2e-6)
+    got = npy(td.reinhard_tonemap(gpu(rgb, dev), gpu(m, dev), td.TonemapParameters(0.75, 2.0, 1.0, 0.3))).astype(np.int32)
+    assert np.abs(got - oracle.tonemap('reinhard', rgb, m, 0.75, 2.0, 1.0, 0.3).astype(np.int32)).max() <= 1
+
+
 def test_rcd_negative_and_pure_function(td, oracle, dev, scene):
     """Negative raw samples are clamped; a second call on the same workspace gives the same
     result (the reference's call-history dependence is not reproduced) in a fresh tensor."""
