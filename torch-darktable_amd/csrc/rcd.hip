@@ -122,18 +122,12 @@ __global__ __launch_bounds__(256) void rcd_border(const T* __restrict__ in, T* _
   border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
-                                                    int tiles_x) {
-  extern __shared__ float lds[];
-  // The first `nborder` workgroups do the border ring (independent of the tiles: disjoint output
-  // pixels, input read-only), so the ring costs a few workgroup slots inside this launch instead
-  // of a latency-bound launch of its own.
-  if ((int)blockIdx.x < nborder) {
-    border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * NT + threadIdx.x);
-    return;
-  }
-  const int tile = (int)blockIdx.x - nborder, tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+// One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
+// (all the `row/col >= k && <= size - k` guards of the nine steps hold for every site the tile
+// touches): the guards compile away, which removes ~10 % of the instructions of 93 % of the tiles.
+template <typename T, bool INTERIOR>
+__device__ __forceinline__ void rcd_tile(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int tile_x, int tile_y,
+                                         float* __restrict__ lds) {
   float* pA = lds;               // cfa
   float* pB = lds + PLANE;       // v_diff, then p_diff at odd columns and q_diff at (odd - 1)
   float* pC = lds + 2 * PLANE;   // h_diff, then step-5.1 colour at R/B sites
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
   for (int i = tid; i < RW * RH; i += NT) {
     const int r = i / RW, c = i - r * RW;
     const int gx = gx0 + c, gy = gy0 + r;
-    pA[r * S + c] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
+    pA[r * S + c] = (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
   }
   __syncthreads();
 
@@ -162,7 +156,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int r = rr + HALO - K, c = cc + HALO - K;
       const int gx = gx0 + c, gy = gy0 + r;
       float vd = 0.0f, hd = 0.0f;
-      if (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4) {
+      if (INTERIOR || (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4)) {
         const float* a = pA + r * S + c;
         vd = sqf(a[-3 * S] - 3.0f * a[-2 * S] - a[-S] + 6.0f * a[0] - a[S] - 3.0f * a[2 * S] + a[3 * S]);
         hd = sqf(a[-3] - 3.0f * a[-2] - a[-1] + 6.0f * a[0] - a[1] - 3.0f * a[2] + a[3]);
@@ -181,7 +175,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int r = rr + HALO - K, c = cc + HALO - K;
       const int gx = gx0 + c, gy = gy0 + r;
       float vh = 0.0f;
-      if (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3) {
+      if (INTERIOR || (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3)) {
         const int q = r * S + c;
         const float eps = 1e-10f;
         const float V_Stat = fmaxf(eps, pB[q - S] + pB[q] + pB[q + S]);
@@ -203,7 +197,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int gy = gy0 + r;
       const int gx = gx0 + c;
       float v = 0.0f;
-      if (gy >= 2 && gy <= h - 2 && gx >= 2 && gx <= w - 2) {
+      if (INTERIOR || (gy >= 2 && gy <= h - 2 && gx >= 2 && gx <= w - 2)) {
         const float* a = pA + r * S + c;
         v = a[0] + 0.5f * (a[-S] + a[S] + a[-1] + a[1]) + 0.25f * (a[-S - 1] + a[-S + 1] + a[S - 1] + a[S + 1]);
       }
@@ -226,7 +220,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int gy = gy0 + r;
       const int gx = gx0 + c;
       float g = 0.0f;
-      if (gy >= 4 && gy <= h - 5 && gx >= 4 && gx <= w - 5) {
+      if (INTERIOR || (gy >= 4 && gy <= h - 5 && gx >= 4 && gx <= w - 5)) {
         const int q = r * S + c;
         const float* a = pA + q;
         const float* L = pE + q;
@@ -259,8 +253,8 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int c = (HALO - K) + 2 * ci + 1;  // odd local column == odd global column
       const int gx = gx0 + c, gy = gy0 + r;
       float pd = 0.0f, qd = 0.0f;
-      if (gx >= 0 && gy >= 0 && gx < w && gy < h) {
-        if (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4) {
+      if (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) {
+        if (INTERIOR || (gy >= 3 && gy <= h - 4 && gx >= 3 && gx <= w - 4)) {
           const float* a = pA + r * S + c;
           pd = sqf((a[-3 * S - 3] - a[-S - 1] - a[S + 1] + a[3 * S + 3]) - 3.0f * (a[-2 * S - 2] + a[2 * S + 2]) + 6.0f * a[0]);
           qd = sqf((a[-3 * S + 3] - a[-S + 1] - a[S - 1] + a[3 * S - 3]) - 3.0f * (a[-2 * S + 2] + a[2 * S - 2]) + 6.0f * a[0]);
@@ -288,7 +282,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int gy = gy0 + r;
       const int gx = gx0 + c;
       float pq = 0.0f;
-      if (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3) {
+      if (INTERIOR || (gy >= 2 && gy <= h - 3 && gx >= 2 && gx <= w - 3)) {
         const int oc0 = c | 1, ocm = (c - 1) | 1;  // odd-column aliases of col and col-1 (local parity == global parity)
         const float eps = 1e-10f;
         const float P_Stat = fmaxf(eps, pB[(r - 1) * S + ocm] + pB[r * S + oc0] + pB[(r + 1) * S + ocm + 2]);
@@ -314,7 +308,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       const int par = c & 1;
       const int gx = gx0 + c;
       float val = 0.0f;
-      if (gy >= 4 && gy <= h - 4 && gx >= 4 && gx <= w - 4) {
+      if (INTERIOR || (gy >= 4 && gy <= h - 4 && gx >= 4 && gx <= w - 4)) {
         const int q = r * S + c;
         const float* a = pA + q;  // rgbc at the diagonal neighbours is their native sample
         // green plane: own site and same-class sites keep their partner parity; the diagonal
@@ -422,13 +416,13 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       if (tid < 512) {
         const int ly = tid >> 4, lx = (tid & 15) * 4;
         const int x = x0 + lx, y = y0 + half * 32 + ly;
-        if (x < w && y >= 7 && y < h - 7 && x + 3 >= 7 && x < w - 7) {
+        if (INTERIOR || (x < w && y >= 7 && y < h - 7 && x + 3 >= 7 && x < w - 7)) {
           float px[12];
           const float4* sp = reinterpret_cast<const float4*>(stg + ly * STG + lx * 3);
           const float4 a = sp[0], b = sp[1], c4 = sp[2];
           px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
           px[8] = c4.x; px[9] = c4.y; px[10] = c4.z; px[11] = c4.w;
-          if ((x >= 7) && (x + 3 < w - 7)) {
+          if (INTERIOR || ((x >= 7) && (x + 3 < w - 7))) {
             store_rgb4(out, x, y, w, vec_ok, px);
           } else {
             for (int k = 0; k < 4; k++) {
@@ -444,6 +438,23 @@ __global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* 
       __syncthreads();
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void rcd_interior(const T* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
+                                                    int tiles_x) {
+  extern __shared__ float lds[];
+  // The first `nborder` workgroups do the border ring (independent of the tiles: disjoint output
+  // pixels, input read-only), so the ring costs a few workgroup slots inside this launch instead
+  // of a latency-bound launch of its own.
+  if ((int)blockIdx.x < nborder) {
+    border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * NT + threadIdx.x);
+    return;
+  }
+  const int tile = (int)blockIdx.x - nborder, tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+  const bool interior = tile_x >= 1 && tile_y >= 1 && tile_x * TW + TW + HALO <= w && tile_y * TH + TH + HALO <= h;
+  if (interior) rcd_tile<T, true>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
+  else rcd_tile<T, false>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
 }
 
 template <typename T>
