@@ -110,6 +110,10 @@ int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, int log_mode
 int tdk_modify_luminance(const void* rgb, const void* lum, void* rgb_out, int64_t npix, int log_mode, int rgb_dtype, int lum_dtype,
                          tdk_stream_t stream);
 
+/* normalize_image of the pipeline: reference torch_darktable/pipeline/util.py:8-10.
+ * out[i] = (in[i] - bounds[0]) / (bounds[1] - bounds[0]) over `count` samples; bounds[2] on device. */
+int tdk_normalize(const void* in, void* out, int64_t count, const float* bounds, int dtype, tdk_stream_t stream);
+
 /* ---- image statistics + tonemaps: reference csrc/tonemap/ (extension.cpp:172-195) */
 /* compute_image_bounds: color_adaption.cu:90-120.  bounds[2] on device; call tdk_image_bounds_init
  * once, then tdk_image_bounds_accumulate per image. */

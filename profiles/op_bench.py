@@ -80,6 +80,17 @@ def main():
     ops['decode12 -> f16'] = (lambda: td.decode12_half(packed, ids_format=False), n * 1.5 + n * 2)
     ops['encode12 <- f32'] = (lambda: td.encode12_float(flat32, ids_format=False), n * 1.5 + n * 4)
 
+    # the caller: packed 12-bit raw bytes -> ImageProcessor -> uint8
+    try:
+        from torch_darktable.pipeline import CameraSettings, ImageProcessingSettings, ImageProcessor, ImageTransform, ToneMapper
+        settings = ImageProcessingSettings(tone_gamma=0.75, tone_intensity=2.0, moving_average=1.0, enable_bilateral=True, tone_mapping=ToneMapper.reinhard)
+        cam = CameraSettings(name='cam', image_size=(w, h), padding=0, white_balance=(1.5, 1.0, 1.2), image_processing=settings, transform=ImageTransform.none)
+        proc = ImageProcessor.from_camera_settings(cam, dev)
+        raw = packed.clone()
+        ops['ImageProcessor.process (packed12 -> u8, defaults + bilateral)'] = (lambda: proc.process(raw, 'cam'), n * 1.5 + n * 3)
+    except Exception as e:  # noqa: BLE001
+        print(json.dumps({'op': 'ImageProcessor.process', 'error': str(e)[:200]}), flush=True)
+
     rows = []
     for name, (fn, nbytes) in ops.items():
         if a.only and a.only.lower() not in name.lower():

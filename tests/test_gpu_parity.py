@@ -397,6 +397,18 @@ def test_fp16_storage_pipeline(td, oracle, dev, scene):
     assert np.abs(npy(u8).astype(np.int32) - ref_u8.astype(np.int32)).max() <= 1
 
 
+def test_normalize_image_kernel(td, dev):
+    from torch_darktable.pipeline.util import normalize_image
+    g = torch.Generator().manual_seed(5)
+    for shape in [(37, 53, 3), (4, 4, 3), (1, 3, 3), (128, 256, 3)]:
+        x = (torch.rand(shape, generator=g) * 3 - 0.5).to(dev)
+        b = torch.tensor([-0.37, 2.11], device=dev)
+        assert torch.equal(normalize_image(x, b), (x - b[0]) / (b[1] - b[0]))
+        xh = x.half()
+        ref = ((xh.float() - b[0]) / (b[1] - b[0])).half()
+        assert torch.equal(normalize_image(xh, b), ref)
+
+
 # ------------------------------------------------------------------ pipeline (caller + on-disk format)
 def test_image_processor_end_to_end(td, oracle, dev, scene, tmp_path):
     """packed 12-bit raw FILE with trailing padding -> ImageProcessor -> uint8, against the oracle

@@ -160,6 +160,23 @@ int run_modify(const void* rgb_, const void* lum_, void* out_, int64_t npix, hip
   return TDK_OK;
 }
 
+// normalize_image of the pipeline (reference torch_darktable/pipeline/util.py:8-10, a torch.compile'd
+// elementwise expression): (x - bounds[0]) / (bounds[1] - bounds[0]) with the bounds on the device.
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, const float* __restrict__ bounds) {
+  const float b0 = bounds[0], range = bounds[1] - bounds[0];
+  const int64_t n4 = n / 4;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n4; g += (int64_t)gridDim.x * 256) {
+    float v[4];
+    s4_io<T>::load(in, (size_t)g, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (v[k] - b0) / range;
+    s4_io<T>::store(out, (size_t)g, v);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) st(out, (size_t)i, (ld(in, (size_t)i) - b0) / range);
+}
+
 }  // namespace
 
 TDK_EXPORT int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
@@ -211,4 +228,14 @@ TDK_EXPORT int tdk_modify_luminance(const void* rgb, const void* lum, void* rgb_
   if (npix == 0) return TDK_OK;
   TDK_REQUIRE(rgb && lum && rgb_out, "tdk_modify_luminance: null pointer");
   TDK_LUM_DISPATCH(run_modify, rgb, lum, rgb_out, npix, tdk_stream(stream));
+}
+
+TDK_EXPORT int tdk_normalize(const void* in, void* out, int64_t count, const float* bounds, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(count >= 0, "tdk_normalize: negative element count");
+  if (count == 0) return TDK_OK;
+  TDK_REQUIRE(in && out && bounds, "tdk_normalize: null pointer");
+  TDK_REQUIRE(tdk_aligned(in, 16) && tdk_aligned(out, 16), "tdk_normalize: buffers must be 16-byte aligned");
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_normalize", normalize_kernel<T>, dim3(stream_grid(count / 4 + 1)), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(in), reinterpret_cast<T*>(out), count, bounds));
+  return TDK_OK;
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
   'tdk_color_op': (c_int, [c_void_p, c_void_p, c_int64, c_int, C.POINTER(c_float), c_void_p, c_void_p]),
   'tdk_compute_luminance': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
   'tdk_modify_luminance': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+  'tdk_normalize': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
   'tdk_image_bounds_init': (c_int, [c_void_p, c_void_p]),
   'tdk_image_bounds_accumulate': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
   'tdk_image_metrics_init': (c_int, [c_void_p, c_void_p]),

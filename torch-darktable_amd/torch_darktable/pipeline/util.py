@@ -11,7 +11,12 @@ def lerp(a: torch.Tensor, b: torch.Tensor, t: float) -> torch.Tensor:
 
 
 def normalize_image(rgb_raw: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
-    """Map [bounds[0], bounds[1]] to [0, 1]; bounds is a 2-element device tensor (no host read-back)."""
+    """Map [bounds[0], bounds[1]] to [0, 1]; bounds is a 2-element device tensor (no host read-back).
+    GPU images take the library's one-pass kernel (same IEEE expression, bit-identical to the torch
+    ops below, which remain for host tensors -- the reference compiles this line with torch.compile)."""
+    if rgb_raw.is_cuda and rgb_raw.dtype in (torch.float32, torch.float16):
+        from ..torch_darktable_extension import normalize_image as _normalize
+        return _normalize(rgb_raw, bounds)
     return (rgb_raw - bounds[0]) / (bounds[1] - bounds[0])
 
 

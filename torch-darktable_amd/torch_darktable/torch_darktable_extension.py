@@ -417,6 +417,19 @@ class TonemapParams:
     return f'TonemapParams(gamma={self.gamma}, intensity={self.intensity}, light_adapt={self.light_adapt}, vibrance={self.vibrance})'
 
 
+def normalize_image(image: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+  """(image - bounds[0]) / (bounds[1] - bounds[0]) in one pass, bounds stay on the device
+  (reference torch_darktable/pipeline/util.py:8-10; not part of the reference's extension module)."""
+  _require(image.is_cuda and image.dtype in (torch.float32, torch.float16), 'image must be a CUDA float32/float16 tensor')
+  _require(bounds.numel() == 2 and bounds.dtype == torch.float32, 'bounds must be 2 float32 values')
+  x = image.contiguous()
+  b = bounds.to(x.device).contiguous()
+  out = torch.empty_like(x)
+  with torch.cuda.device(x.device):
+    check(lib.tdk_normalize(_ptr(x), _ptr(out), x.numel(), _ptr(b), _dtype_tag(x), _stream()))
+  return out
+
+
 def compute_image_bounds(images: Sequence[torch.Tensor], stride: int = 8) -> torch.Tensor:
   _require(len(images) > 0, 'images must be non-empty')
   dev = images[0].device
