@@ -45,6 +45,9 @@ def main():
     lum32 = lum.float()
     post = td.PostProcess(dev, (w, h), td.BayerPattern.RGGB, color_smoothing_passes=3, green_eq_local=True, green_eq_global=False)
     wiener = td.Wiener(dev, (w, h), 4, 32)
+    wiener16 = td.Wiener(dev, (w, h), 4, 16)
+    wiener_ov8 = td.Wiener(dev, (w, h), 8, 32)
+    wiener_ov2 = td.Wiener(dev, (w, h), 2, 32)
     bil2 = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
     bil8 = td.Bilateral(dev, (w, h), sigma_s=8.0, sigma_r=0.1)
     from torch_darktable.local_contrast import LaplacianParams
@@ -65,6 +68,9 @@ def main():
         'compute_luminance': (lambda: td.compute_luminance(rgb), n * 4 * s),
         'modify_luminance': (lambda: td.modify_luminance(rgb, lum), n * 7 * s),
         'Wiener.process C=1 (K=32, ov=4)': (lambda: wiener.process(lum.unsqueeze(2), 0.075), n * 2 * s),
+        'Wiener.process C=1 (K=16, ov=4)': (lambda: wiener16.process(lum.unsqueeze(2), 0.075), n * 2 * s),
+        'Wiener.process C=1 (K=32, ov=8)': (lambda: wiener_ov8.process(lum.unsqueeze(2), 0.075), n * 2 * s),
+        'Wiener.process C=1 (K=32, ov=2)': (lambda: wiener_ov2.process(lum.unsqueeze(2), 0.075), n * 2 * s),
         'Wiener.process C=3 (K=32, ov=4)': (lambda: wiener.process(rgb, 0.05), n * 6 * s),
         'Wiener.process_log_luminance': (lambda: wiener.process_log_luminance(rgb, 0.075), n * 6 * s),
         'Bilateral.process (2.0, 0.2)': (lambda: bil2.process(lum, 0.4), n * 2 * s),

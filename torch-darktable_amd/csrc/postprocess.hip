@@ -189,39 +189,54 @@ __global__ __launch_bounds__(256) void green_apply_kernel(const float* __restric
     }
 }
 
-// postprocess.cu:84-169; threshold already divided by 100
+// postprocess.cu:84-169; threshold already divided by 100.  One workgroup = 64 x 16 pixels: the
+// green channel of the tile + 2-px halo is staged in LDS once (zero outside the image, as the
+// reference's guarded loads), so the eight neighbour greens of a G2 site are LDS reads instead of
+// eight strided gathers from the interleaved image.
+constexpr int GLW = 64, GLH = 16, GLS = GLW + 4 + 1;
+
 template <int VEC>
 __global__ __launch_bounds__(256) void green_local_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
                                                           uint32_t pattern, float threshold) {
-  const int ngroup = width / VEC;
-  for (int y = blockIdx.y; y < height; y += gridDim.y)
-    for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroup; gi += gridDim.x * 256) {
-      const size_t g4 = (size_t)y * ngroup + gi;
-      float v[3 * VEC];
-      if constexpr (VEC == 4) rgb4_io<float>::load(in, g4, v);
-      else { v[0] = in[g4 * 3]; v[1] = in[g4 * 3 + 1]; v[2] = in[g4 * 3 + 2]; }
+  __shared__ float gt[(GLH + 4) * GLS];
+  const int x0 = blockIdx.x * GLW, y0 = blockIdx.y * GLH;
+  for (int i = threadIdx.x; i < (GLW + 4) * (GLH + 4); i += 256) {
+    const int r = i / (GLW + 4), c = i - r * (GLW + 4);
+    const int gx = x0 - 2 + c, gy = y0 - 2 + r;
+    gt[r * GLS + c] = (gx >= 0 && gy >= 0 && gx < width && gy < height) ? in[((size_t)gy * width + gx) * 3 + 1] : 0.0f;
+  }
+  __syncthreads();
+  // VEC == 4: 16 threads x 4 px per row, 16 rows; VEC == 1: 64 threads per row, 4 rows per pass
+  constexpr int TPR = GLW / VEC, RPP = 256 / TPR;
+  const int lx = (threadIdx.x % TPR) * VEC;
+  for (int ly = threadIdx.x / TPR; ly < GLH; ly += RPP) {
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= width || y >= height) continue;
+    const size_t p0 = (size_t)y * width + x;
+    float v[3 * VEC];
+    if constexpr (VEC == 4) rgb4_io<float>::load(in, p0 >> 2, v);
+    else { v[0] = in[p0 * 3]; v[1] = in[p0 * 3 + 1]; v[2] = in[p0 * 3 + 2]; }
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        const int x = gi * VEC + k;
-        float o = v[3 * k + 1];
-        if (cfa_color(y, x, pattern) == 1 && (y & 1)) {
-          auto g0 = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < width && yy < height) ? in[((size_t)yy * width + xx) * 3 + 1] : 0.0f; };
-          const float maximum = 1.0f;
-          const float o1_1 = g0(x - 1, y - 1), o1_2 = g0(x + 1, y - 1), o1_3 = g0(x - 1, y + 1), o1_4 = g0(x + 1, y + 1);
-          const float o2_1 = g0(x, y - 2), o2_2 = g0(x, y + 2), o2_3 = g0(x - 2, y), o2_4 = g0(x + 2, y);
-          const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
-          const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
-          if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
-            const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4) + fabsf(o1_2 - o1_4)) / 6.0f;
-            const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4) + fabsf(o2_2 - o2_4)) / 6.0f;
-            if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
-          }
+    for (int k = 0; k < VEC; k++) {
+      float o = v[3 * k + 1];
+      if (cfa_color(y, x + k, pattern) == 1 && (y & 1)) {
+        const float* g = gt + (ly + 2) * GLS + (lx + k + 2);
+        const float maximum = 1.0f;
+        const float o1_1 = g[-GLS - 1], o1_2 = g[-GLS + 1], o1_3 = g[GLS - 1], o1_4 = g[GLS + 1];
+        const float o2_1 = g[-2 * GLS], o2_2 = g[2 * GLS], o2_3 = g[-2], o2_4 = g[2];
+        const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
+        const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
+        if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
+          const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4) + fabsf(o1_2 - o1_4)) / 6.0f;
+          const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4) + fabsf(o2_2 - o2_4)) / 6.0f;
+          if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
         }
-        v[3 * k + 1] = fmaxf(o, 0.0f);
       }
-      if constexpr (VEC == 4) rgb4_io<float>::store(out, g4, v);
-      else { out[g4 * 3] = v[0]; out[g4 * 3 + 1] = v[1]; out[g4 * 3 + 2] = v[2]; }
+      v[3 * k + 1] = fmaxf(o, 0.0f);
     }
+    if constexpr (VEC == 4) rgb4_io<float>::store(out, p0 >> 2, v);
+    else { out[p0 * 3] = v[0]; out[p0 * 3 + 1] = v[1]; out[p0 * 3 + 2] = v[2]; }
+  }
 }
 
 // white_balance.cu:10-42
@@ -301,8 +316,9 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
     float* dst = dst_of(stage++);
     // postprocess.cu:383: threshold / 100. is evaluated in double and narrowed
     const float thr = (float)((double)green_eq_threshold / 100.0);
-    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<4>, row_grid(width / 4, height), dim3(256), 0, s, src, dst, width, height, pattern, thr);
-    else TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<1>, row_grid(width, height), dim3(256), 0, s, src, dst, width, height, pattern, thr);
+    const dim3 lgrid(tdk_div_up(width, GLW), tdk_div_up(height, GLH));
+    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<4>, lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
+    else TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<1>, lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
     src = dst;
   }
   return TDK_OK;
