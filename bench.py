@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument('--width', type=int, default=W12)
     ap.add_argument('--height', type=int, default=H12)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='rehearsal: create the RCCL process group and run the barriers / max-reduce even with one rank')
     ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-kernel event timer off in the timed region')
     return ap.parse_args()
 
@@ -147,14 +148,29 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    torch.cuda.set_device(dev)  # before the process group: RCCL binds the communicator to the current device
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # RCCL printf()s its version banner to STDOUT when the communicator is created (NCCL_DEBUG=VERSION
+        # is exported on these boxes); stdout must carry exactly one JSON line, so fd 1 points at stderr
+        # until the communicator exists.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import __graft_entry__
 
@@ -194,8 +210,8 @@ def main():
         table = _native.profile_report()
         _native.profile_enable(False)
         dom = max(table.items(), key=lambda kv: kv[1][1])[0]
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     if use_timer:
         _native.profile_enable(True, only=dom)
@@ -207,14 +223,14 @@ def main():
     report = _native.profile_report() if use_timer else {}
     if use_timer:
         _native.profile_enable(False)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -277,7 +293,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out['cpu_baseline'] = {'value': None, 'unit': 'MP/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {e}'}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

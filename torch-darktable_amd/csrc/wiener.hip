@@ -219,9 +219,8 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
   const int nsteps = ov >> 1;
 
   // Work item = (group, step).  Persistent workgroups (one per CU: the LDS footprint allows no
-  // more) walk the groups with a grid stride; the rows of the NEXT item are fetched into
-  // registers while the current one is transformed, so HBM/L2 latency never sits on the
-  // critical path of the 2-waves-per-SIMD schedule.
+  // more) walk the groups with a grid stride.  (Fetching the rows of the NEXT item into registers
+  // during the transforms was measured slower: 253 VGPRs, 0.58 vs 0.29 ms.)
   struct Item {
     int txa, txb, oxa, oxb;
     bool act_a, act_b;
@@ -257,12 +256,6 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
     }
   };
 
-#ifndef TDK_WIENER_PREFETCH
-#define TDK_WIENER_PREFETCH 0
-#endif
-  float nre[K], nim[K];  // prefetched rows of the next item
-  Item cur = make_item((int)blockIdx.x, 0);
-  if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
 
   for (int grp = blockIdx.x; grp < total_groups; grp += gridDim.x) {
     const float sigma = sigmas[chan + grp / ngroups];
@@ -278,16 +271,8 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
     // the plain read-modify-writes below never collide.
     for (int base = 0; base < nsteps; base++) {
       float re[K], im[K];
-      const Item it = cur;
-      if (TDK_WIENER_PREFETCH) {
-#pragma unroll
-        for (int k = 0; k < K; k++) { re[k] = nre[k]; im[k] = nim[k]; }
-      } else {
-        fetch(it, re, im);
-      }
-      // issue the next item's loads now; they complete under the transforms below
-      cur = (base + 1 < nsteps) ? make_item(grp, base + 1) : make_item(grp + (int)gridDim.x, 0);
-      if (TDK_WIENER_PREFETCH) fetch(cur, nre, nim);
+      const Item it = make_item(grp, base);
+      fetch(it, re, im);
 
       float mean_a, mean_b;
       {
