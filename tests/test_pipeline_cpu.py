@@ -101,3 +101,27 @@ def test_util_and_file_lookup(td, tmp_path):
     f.write_bytes(bytes(7))
     with pytest.raises(ValueError):
         settings_for_file(f, cams)
+
+
+def test_pipeline_helpers_match_reference_fixtures(td):
+    """pipeline/util.py and pipeline/transform.py against outputs of the reference's own functions
+    (tests/golden/make_golden.py -> reference_helpers.npz)."""
+    import numpy as np
+
+    from torch_darktable.pipeline.transform import ImageTransform, transform, transformed_size
+    from torch_darktable.pipeline.util import lerp, normalize_image, resize, resize_longest_edge
+
+    g = np.load(Path(__file__).parent / 'golden' / 'reference_helpers.npz')
+    img, bounds = torch.from_numpy(g['pipe_img']), torch.from_numpy(g['pipe_bounds'])
+    assert np.array_equal(normalize_image(img, bounds).numpy(), g['pipe_normalized'])
+    assert np.array_equal(lerp(img, img.flip(0), 0.3).numpy(), g['pipe_lerp'])
+    assert np.allclose(resize(img, (4, 5)).numpy(), g['pipe_resized'], rtol=0, atol=1e-6)
+    sizes = [tuple(int(v) for v in s) for s in g['pipe_resize_sizes_in']]
+    got = [[*resize_longest_edge(s, L)] for s in sizes for L in (0, 512, 1000)]
+    assert np.array_equal(np.array(got), g['pipe_resize_sizes_out'])
+    small = torch.from_numpy(g['pipe_transform_in'])
+    for t in ImageTransform:
+        out = transform(small, t)
+        assert out.is_contiguous() and np.array_equal(out.numpy(), g[f'pipe_transform_{t.name}'])
+        assert np.array_equal(np.array(transformed_size((640, 480), t)), g[f'pipe_transformed_size_{t.name}'])
+        assert t.next_rotation().value == int(g[f'pipe_next_rotation_{t.name}'])
