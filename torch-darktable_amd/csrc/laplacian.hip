@@ -99,14 +99,14 @@ __device__ __forceinline__ float curve(float x, float g, const CurveK& k) {
 
 // Level 0 -> level 1 of the six gamma pyramids in one pass: the padded input is read once, the six
 // remap curves are evaluated per fine pixel into LDS (rounded to binary16, exactly what the
-// reference stores as level 0 of each gamma pyramid), and each thread reduces one coarse pixel of
-// each gamma with the same 25-tap order as reduce_at.  The six full-resolution curve images
+// reference stores as level 0 of each gamma pyramid), then reduced separably (rows, then columns).  The six full-resolution curve images
 // (6 x 63 MB written and read back at 12 MP) never exist.
 constexpr int RTW = 32, RTH = 8, RFW = 2 * RTW + 3, RFH = 2 * RTH + 3, RFS = RFW + 1;
 
 __global__ __launch_bounds__(256) void curves_reduce6_kernel(const __half* __restrict__ padded, Ptr6 coarse, int fw, int cw, int ch, float sigma,
                                                              float shadows, float highlights, float clarity) {
   __shared__ __half fine[NG][RFH * RFS];
+  __shared__ float hrow[NG][RFH * RTW];
   const CurveK ck = make_curve(sigma, shadows, highlights, clarity);
   const int CX0 = blockIdx.x * RTW, CY0 = blockIdx.y * RTH;
   auto clampc = [](int p, int n) { int c = p; if (p >= n - 1) c = n - 2; if (c <= 0) c = 1; return c; };  // reduce_at's centre clamp
@@ -121,17 +121,29 @@ __global__ __launch_bounds__(256) void curves_reduce6_kernel(const __half* __res
     for (int k = 0; k < NG; k++) fine[k][r * RFS + c] = __float2half_rn(curve(v, ((float)k + 0.5f) / (float)NG, ck));
   }
   __syncthreads();
-  const int px = CX0 + (threadIdx.x & (RTW - 1)), py = CY0 + threadIdx.x / RTW;
-  if (px >= cw || py >= ch) return;
-  const int lx = 2 * clampc(px, cw) - fx0, ly = 2 * clampc(py, ch) - fy0;
+  // separable 5 x 5: horizontal sums of every fine row at the tile's 32 coarse columns, then the
+  // vertical combination (9 + 9 instead of 25 multiply-adds per output; the summation order differs
+  // from reduce_at's -- far below the binary16 rounding of the result)
   const float w5[5] = {1.0f / 16.0f, 4.0f / 16.0f, 6.0f / 16.0f, 4.0f / 16.0f, 1.0f / 16.0f};
+  for (int i = threadIdx.x; i < NG * RFH * RTW; i += 256) {
+    const int pxl = i & (RTW - 1), kr = i / RTW, k = kr / RFH, r = kr - k * RFH;
+    const int px = min(CX0 + pxl, cw - 1);
+    const __half* row = &fine[k][r * RFS + 2 * clampc(px, cw) - fx0];
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = -2; t <= 2; t++) acc += __half2float(row[t]) * w5[t + 2];
+    hrow[k][r * RTW + pxl] = acc;
+  }
+  __syncthreads();
+  const int pxl = threadIdx.x & (RTW - 1);
+  const int px = CX0 + pxl, py = CY0 + threadIdx.x / RTW;
+  if (px >= cw || py >= ch) return;
+  const int ly = 2 * clampc(py, ch) - fy0;
 #pragma unroll
   for (int k = 0; k < NG; k++) {
     float acc = 0.0f;
 #pragma unroll
-    for (int j = -2; j <= 2; j++)
-#pragma unroll
-      for (int i = -2; i <= 2; i++) acc += __half2float(fine[k][(ly + j) * RFS + lx + i]) * w5[i + 2] * w5[j + 2];
+    for (int j = -2; j <= 2; j++) acc += hrow[k][(ly + j) * RTW + pxl] * w5[j + 2];
     hst(coarse.p[k], px, py, cw, acc);
   }
 }
@@ -153,7 +165,7 @@ __device__ __forceinline__ float expand_gaussian(const __half* __restrict__ coar
 }
 
 // laplacian.cu:53-65
-__device__ __forceinline__ int clamp_boundary(int q, int n) {
+__host__ __device__ __forceinline__ int clamp_boundary(int q, int n) {
   if (n & 1) { if (q > n - 2) q = n - 2; } else { if (q > n - 3) q = n - 3; }
   if (q <= 0) q = 1;
   return q;
@@ -190,10 +202,10 @@ constexpr int ATW = 64, ATH = 16, ACW = ATW / 2 + 3, ACH = ATH / 2 + 3, ACS = AC
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void assemble_tiled_kernel(const __half* __restrict__ input, const __half* __restrict__ out_coarse,
                                                              __half* __restrict__ out_fine, CPtr6 g_fine, CPtr6 g_coarse, int fw, int fh, float sigma,
-                                                             float shadows, float highlights, float clarity) {
+                                                             float shadows, float highlights, float clarity, int tile_x0, int tile_y0) {
   __shared__ float tiles[(NG + 1) * ACH * ACS];
   const CurveK ck = make_curve(sigma, shadows, highlights, clarity);
-  const int X0 = blockIdx.x * ATW, Y0 = blockIdx.y * ATH;
+  const int X0 = (blockIdx.x + tile_x0) * ATW, Y0 = (blockIdx.y + tile_y0) * ATH;
   const int cw = (fw - 1) / 2 + 1, chh = (fh - 1) / 2 + 1;
   const int X1 = min(X0 + ATW, fw) - 1, Y1 = min(Y0 + ATH, fh) - 1;
   // coarse cells touched: clamp_boundary is monotone, taps are cx - 1 .. cx + 1
@@ -323,17 +335,31 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     TDK_LAUNCH("tdk_laplacian(reduce6)", reduce_kernel, g, dim3(256), 0, s, f, c, fw, cw, ch);
   }
 
+  // The output pyramid is only consumed downwards, and only write_back reads level 0 -- inside the
+  // un-padded image.  So level l is assembled only on the rectangle the level below expands from
+  // (clamp_boundary, taps cx - 1 .. cx + 1), starting from the image rectangle at level 0: most of
+  // the 2.5x padded area is never assembled at the fine levels.
+  struct Rect { int x0, x1, y0, y1; };  // inclusive
+  Rect need[MAX_LEVELS + 1];
+  need[0] = Rect{L.pad, L.pad + width - 1, L.pad, L.pad + height - 1};
+  for (int l = 0; l + 1 < L.levels; l++) {
+    const int fw = dl(L.bw, l), fh = dl(L.bh, l), cw = (fw - 1) / 2 + 1, chh = (fh - 1) / 2 + 1;
+    auto lo = [](int v) { return v > 0 ? v : 0; };
+    need[l + 1] = Rect{lo(clamp_boundary(need[l].x0, fw) / 2 - 1), (clamp_boundary(need[l].x1, fw) / 2 + 1 < cw - 1) ? clamp_boundary(need[l].x1, fw) / 2 + 1 : cw - 1,
+                       lo(clamp_boundary(need[l].y0, fh) / 2 - 1), (clamp_boundary(need[l].y1, fh) / 2 + 1 < chh - 1) ? clamp_boundary(need[l].y1, fh) / 2 + 1 : chh - 1};
+  }
   for (int l = L.levels - 2; l >= 0; l--) {
     const int pw = dl(L.bw, l), ph = dl(L.bh, l);
     CPtr6 gf, gc;
     for (int k = 0; k < NG; k++) { gf.p[k] = proc(k, l); gc.p[k] = proc(k, l + 1); }
-    const dim3 g(tdk_div_up(pw, ATW), tdk_div_up(ph, ATH));
+    const int tx0 = need[l].x0 / ATW, tx1 = need[l].x1 / ATW, ty0 = need[l].y0 / ATH, ty1 = need[l].y1 / ATH;
+    const dim3 g(tx1 - tx0 + 1, ty1 - ty0 + 1);
     if (l == 0)
       TDK_LAUNCH("tdk_laplacian(assemble)", assemble_tiled_kernel<true>, g, dim3(256), 0, s, padded(l), output(l + 1), output(l), gf, gc, pw, ph, sigma, shadows,
-                 highlights, clarity);
+                 highlights, clarity, tx0, ty0);
     else
       TDK_LAUNCH("tdk_laplacian(assemble)", assemble_tiled_kernel<false>, g, dim3(256), 0, s, padded(l), output(l + 1), output(l), gf, gc, pw, ph, sigma, shadows,
-                 highlights, clarity);
+                 highlights, clarity, tx0, ty0);
   }
 
   TDK_LAUNCH("tdk_laplacian(write_back)", write_back_kernel, grid2(width, height), dim3(256), 0, s, output(0), lum_out, width, height, L.pad, L.bw);
