@@ -451,3 +451,33 @@ def test_image_processor_end_to_end(td, oracle, dev, scene, tmp_path):
     m0 = proc.metrics.clone()
     proc.process(load_raw_bytes(raw_file, dev), 'cam')
     assert torch.allclose(proc.metrics, m0)
+
+
+def test_raw_frame_stream_prefetch(td, dev, tmp_path):
+    """Pinned-ring / copy-stream prefetcher: frames arrive in order and intact from
+    files, bytes and tensors; wrong sizes are reported; abandoning the iterator does not hang."""
+    from torch_darktable.pipeline import RawFrameStream
+
+    n, nb = 7, 96 * 128 * 3 // 2 + 64
+    rng = np.random.default_rng(7)
+    blobs = [rng.integers(0, 256, nb, dtype=np.uint8) for _ in range(n)]
+    paths = []
+    for i, b in enumerate(blobs):
+        p = tmp_path / f'frame{i}.raw'
+        p.write_bytes(b.tobytes())
+        paths.append(p)
+    sources = [paths[0], blobs[1].tobytes(), torch.from_numpy(blobs[2]), *paths[3:]]
+    for depth in (1, 2, 4):
+        got = []
+        for frame in RawFrameStream(sources, dev, nb, depth=depth):
+            assert frame.device == dev and frame.dtype == torch.uint8
+            got.append(frame.clone())  # consumer-stream work on the yielded buffer
+        torch.cuda.synchronize()
+        assert len(got) == n and all(np.array_equal(npy(g), b) for g, b in zip(got, blobs))
+    it = iter(RawFrameStream(paths, dev, nb, depth=2))
+    assert np.array_equal(npy(next(it)), blobs[0])
+    it.close()  # early exit: reader thread must shut down
+    with pytest.raises(ValueError):
+        list(RawFrameStream([paths[0], b'short'], dev, nb))
+    with pytest.raises(ValueError):
+        RawFrameStream(paths, torch.device('cpu'), nb)
