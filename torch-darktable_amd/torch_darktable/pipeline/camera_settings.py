@@ -8,6 +8,7 @@ directory name or, failing that, by its exact size."""
 from __future__ import annotations
 
 from pathlib import Path
+import threading
 from typing import Annotated, Literal
 import warnings
 
@@ -55,13 +56,37 @@ class CameraSettings(BaseModel, frozen=True):
         return cls.model_validate_json(Path(path).read_text())
 
 
+_staging_lock = threading.Lock()
+_staging: dict = {}  # (device index, nbytes) -> [pinned host buffer, event of the last upload out of it]
+
+
 def load_raw_bytes(filepath: Path, device: torch.device = torch.device('cuda:0')) -> torch.Tensor:
-    """Whole file -> uint8 device tensor (pinned staging + async copy; no decoding)."""
-    data = Path(filepath).read_bytes()
-    host = torch.frombuffer(data, dtype=torch.uint8)
-    if torch.device(device).type == 'cuda':
-        host = host.pin_memory()
-    return host.to(device, non_blocking=True)
+    """Whole file -> uint8 device tensor (no decoding).  The file is read straight into a cached
+    pinned staging buffer (pinning 19 MB per call costs more than the upload) and copied
+    asynchronously on the current stream; the buffer is reused once its previous upload has finished.
+    For sustained throughput use pipeline.RawFrameStream, which also overlaps the reads."""
+    path = Path(filepath)
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.frombuffer(bytearray(path.read_bytes()), dtype=torch.uint8)
+    nbytes = path.stat().st_size
+    with _staging_lock, torch.cuda.device(device):
+        key = (torch.cuda.current_device(), nbytes)
+        if key not in _staging:
+            if len(_staging) >= 8:  # a handful of camera formats at most; do not hoard pinned memory
+                _staging.pop(next(iter(_staging)))
+            _staging[key] = [torch.empty(nbytes, dtype=torch.uint8).pin_memory(), None]
+        host, last = _staging[key]
+        if last is not None:
+            last.synchronize()
+        with open(path, 'rb') as f:
+            if f.readinto(host.numpy()) != nbytes:
+                raise OSError(f'{path}: short read')
+        out = host.to(device, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        _staging[key][1] = done
+    return out
 
 
 def load_raw_bytes_stripped(filepath: Path, camera_settings: CameraSettings, device: torch.device = torch.device('cuda:0')) -> torch.Tensor:

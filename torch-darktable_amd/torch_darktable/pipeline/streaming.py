@@ -13,6 +13,7 @@ takes.
 from __future__ import annotations
 
 import queue
+import sys
 import threading
 from collections.abc import Iterable, Iterator
 from pathlib import Path
@@ -32,7 +33,7 @@ class RawFrameStream:
     """
 
     def __init__(self, sources: Iterable[Path | str | bytes | torch.Tensor], device: torch.device, frame_bytes: int, depth: int = 4,
-                 readers: int = 4):
+                 readers: int = 2):
         if depth < 1 or readers < 1:
             raise ValueError('depth and readers must be >= 1')
         self.device = torch.device(device)
@@ -113,6 +114,11 @@ class RawFrameStream:
                         cond.notify_all()
 
         workers = [threading.Thread(target=reader, name=f'raw-frame-reader-{t}', daemon=True) for t in range(self.readers)]
+        # The consumer is a busy Python thread (it enqueues ~40 kernels per frame and never blocks), and a
+        # reader needs the GIL for a few statements between its blocking calls: with CPython's default
+        # 5 ms switch interval each hand-over can cost a frame time.  Shorten it while streaming.
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))
         for t in workers:
             t.start()
         try:
@@ -139,3 +145,4 @@ class RawFrameStream:
                 cond.notify_all()
             for t in workers:
                 t.join(timeout=5.0)
+            sys.setswitchinterval(old_interval)
