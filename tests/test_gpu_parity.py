@@ -358,14 +358,20 @@ def test_bilateral_tiny_images(td, oracle, dev, scene, size, sig):
     assert np.array_equal(npy(ws.process(gpu(lum, dev), 0.5)), oracle.bilateral(lum, sig[0], sig[1], 0.5))
 
 
-def test_wiener_log_luminance_pipeline(td, oracle, dev, scene):
-    h, w = 96, 128
+@pytest.mark.parametrize('size', [(96, 128), (50, 77), (33, 70)])
+def test_wiener_log_luminance_pipeline(td, oracle, dev, scene, size):
+    """Fused extract -> tiles -> finish+modify; odd widths take the scalar (non-vector) epilogue.
+    The fused call must also equal the three-call chain it replaces."""
+    h, w = size
     img = scene(h, w, 27)
     ws = td.Wiener(dev, (w, h))
-    got = npy(ws.process_log_luminance(gpu(img, dev), 0.075))
+    x = gpu(img, dev)
+    got = npy(ws.process_log_luminance(x, 0.075))
     ll = oracle.compute_luminance(img, True, 1e-4)
     ref = oracle.modify_luminance(img, oracle.wiener(ll[:, :, None], 0.075)[:, :, 0], True)
     assert np.abs(got - ref).max() < 2e-4
+    chain = td.modify_log_luminance(x, ws.process(td.compute_log_luminance(x, 1e-4).unsqueeze(2), 0.075).squeeze(2), 1e-4)
+    assert np.abs(got - npy(chain)).max() < 2e-6
 
 
 @pytest.mark.parametrize('prm', [(0.2, 1.0, 1.0, 0.0), (0.2, 1.6, 0.7, 0.3), (0.35, 0.5, 1.5, -0.2)])
