@@ -340,14 +340,12 @@ __device__ __forceinline__ void rcd_tile(const T* __restrict__ in, T* __restrict
   __syncthreads();
 
   // ---- P6: step 5.2 at green sites + write_output (margin 7), half a tile (32 rows) at a time.
-  // Compute pass: one lane per COLUMN of a 2-row band (checkerboard, as above) produces the
-  // band's green site and R/B site of that column and parks the finished pixels in an LDS staging
-  // area (the p/q plane is dead by now); store pass: one lane per 4 consecutive pixels reads
-  // 48 contiguous staged bytes and writes them with 16-B global stores.
+  // One lane per COLUMN of a 2-row band (checkerboard, as above) produces the band's green site and
+  // R/B site of that column; the two pixels are then sorted by ROW, so that for each row the wave
+  // holds 64 consecutive pixels and writes them straight to HBM as one contiguous run (fp32: 12 B
+  // per lane; fp16: even lanes write their own and their right neighbour's pixel as 12 B).  No LDS
+  // staging, no barrier inside the phase.
   {
-    constexpr int STG = TW * 3 + 4;  // staging row stride in floats (16-B aligned rows)
-    float* stg = pB;
-    static_assert(32 * STG <= PLANE, "staging must fit in one plane");
     for (int half = 0; half < 2; half++) {
       {
         const int bnd = tid >> 6, cc = tid & 63;
@@ -355,15 +353,15 @@ __device__ __forceinline__ void rcd_tile(const T* __restrict__ in, T* __restrict
         const int c = cc + HALO;
         const int par_a = rb_par(y0 + ty_a);             // R/B column parity of row ty_a
         const int rb_off = ((c & 1) ^ par_a) & 1;        // row (0/1 inside the band) of this column's R/B site
+        float rbpx[3], gpx[3];
         // --- R/B site: native, green from step 3.1, other colour from step 5.1
         {
           const int ty = ty_a + rb_off, r = ty + HALO, q = r * S + c;
           const int row_color = cfa_color(y0 + ty, c & 1, pattern);  // colour of this row's R/B sites
           const float native = pA[q], green = pE[r * S + (c ^ 1)], other = pC[q];
-          float* o = stg + (ty - half * 32) * STG + cc * 3;
-          o[0] = fmaxf(row_color == 0 ? native : other, 0.0f);
-          o[1] = fmaxf(green, 0.0f);
-          o[2] = fmaxf(row_color == 0 ? other : native, 0.0f);
+          rbpx[0] = fmaxf(row_color == 0 ? native : other, 0.0f);
+          rbpx[1] = fmaxf(green, 0.0f);
+          rbpx[2] = fmaxf(row_color == 0 ? other : native, 0.0f);
         }
         // --- green site: step 5.2
         {
@@ -406,36 +404,37 @@ __device__ __forceinline__ void rcd_tile(const T* __restrict__ in, T* __restrict
             const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
             res[ci] = g + mixf(V_Est, H_Est, VH_Disc);
           }
-          float* o = stg + (ty - half * 32) * STG + cc * 3;
-          o[0] = fmaxf(res[0], 0.0f);
-          o[1] = fmaxf(g, 0.0f);
-          o[2] = fmaxf(res[1], 0.0f);
+          gpx[0] = fmaxf(res[0], 0.0f);
+          gpx[1] = fmaxf(g, 0.0f);
+          gpx[2] = fmaxf(res[1], 0.0f);
         }
-      }
-      __syncthreads();
-      if (tid < 512) {
-        const int ly = tid >> 4, lx = (tid & 15) * 4;
-        const int x = x0 + lx, y = y0 + half * 32 + ly;
-        if (INTERIOR || (x < w && y >= 7 && y < h - 7 && x + 3 >= 7 && x < w - 7)) {
-          float px[12];
-          const float4* sp = reinterpret_cast<const float4*>(stg + ly * STG + lx * 3);
-          const float4 a = sp[0], b = sp[1], c4 = sp[2];
-          px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
-          px[8] = c4.x; px[9] = c4.y; px[10] = c4.z; px[11] = c4.w;
-          if (INTERIOR || ((x >= 7) && (x + 3 < w - 7))) {
-            store_rgb4(out, x, y, w, vec_ok, px);
-          } else {
-            for (int k = 0; k < 4; k++) {
-              const int gx = x + k;
-              if (gx >= 7 && gx < w - 7) {
-                const size_t p = (size_t)y * w + gx;
-                st(out, p * 3, px[3 * k]); st(out, p * 3 + 1, px[3 * k + 1]); st(out, p * 3 + 2, px[3 * k + 2]);
+        // --- sort by row and write: row ty_a holds this column's R/B pixel when rb_off == 0, else its green pixel
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          const bool take_rb = (rb_off == rr);
+          const float v0 = take_rb ? rbpx[0] : gpx[0], v1 = take_rb ? rbpx[1] : gpx[1], v2 = take_rb ? rbpx[2] : gpx[2];
+          const int x = x0 + cc, y = y0 + ty_a + rr;
+          const size_t p = (size_t)y * w + x;
+          if constexpr (INTERIOR) {
+            if constexpr (sizeof(T) == 4) {
+              struct alignas(4) px3 { float a, b, c; };
+              *reinterpret_cast<px3*>(reinterpret_cast<float*>(out) + p * 3) = px3{v0, v1, v2};
+            } else {
+              // the right neighbour's pixel via DPP quad_perm(1, 0, 3, 2): lane i reads lane i ^ 1
+              const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v0), 0xB1, 0xF, 0xF, true));
+              const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v1), 0xB1, 0xF, 0xF, true));
+              const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v2), 0xB1, 0xF, 0xF, true));
+              if ((cc & 1) == 0) {  // x0 and w are even: p is even, the 12-B pair starts on a 4-B boundary
+                const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, n0), h2 = __floats2half2_rn(n1, n2);
+                struct alignas(4) pair6 { __half2 a, b, c; };
+                *reinterpret_cast<pair6*>(reinterpret_cast<__half*>(out) + p * 3) = pair6{h0, h1, h2};
               }
             }
+          } else if (x < w && y >= 7 && y < h - 7 && x >= 7 && x < w - 7) {
+            st(out, p * 3, v0); st(out, p * 3 + 1, v1); st(out, p * 3 + 2, v2);
           }
         }
       }
-      __syncthreads();
     }
   }
 }
