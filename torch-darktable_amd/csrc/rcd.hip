@@ -17,13 +17,15 @@
 // MI355X design: one 1024-thread workgroup per 64 x 64 output tile.  The CFA tile plus a 10-px
 // halo (the dependency radius of step 5.2 back to the raw data) is read once, coalesced, into
 // LDS; the nine RCD steps then run back to back on five LDS planes (cfa | v_diff->p/q_diff |
-// h_diff->step-5.1 colour | VH_dir | lpf->PQ_dir + green@R/B) with plane-lifetime reuse, and
-// each thread finally writes four finished RGB pixels as three 16-B stores.  HBM sees the
-// compulsory 4 B/px read (+halo from L2) and 12 B/px write.  LDS: 5 x 84 x 85 x 4 B = 142.8 KB,
-// i.e. one workgroup (16 waves) per CU.  The [0,7) border ring (3x3 average + PPG-style
-// green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is a second, tiny kernel over the ring
-// pixels only.  Arithmetic: same operation order as the oracle, no FMA contraction, IEEE
-// divides -> bit-exact.
+// h_diff->step-5.1 colour | VH_dir | lpf->PQ_dir + green@R/B) with plane-lifetime reuse.  In the
+// last phase a wave owns a 2-row band: it sorts its finished pixels by row and writes each row
+// as one contiguous run straight to HBM (no staging).  Tiles clear of the image border run a
+// variant without border guards.  HBM sees the compulsory 4 B/px read (+halo from L2) and
+// 12 B/px write.  LDS: 5 x 84 x 86 x 4 B = 144.5 KB, i.e. one workgroup (16 waves) per CU -- a
+// four-plane / 64 x 32 / two-workgroup variant was measured slower (more halo work).  The [0,7)
+// border ring (3x3 average + PPG-style green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is
+// computed by the first ~100 workgroups of the same launch.  Arithmetic: same operation order as
+// the oracle, no FMA contraction, IEEE divides -> bit-exact.
 #include "tdk_stencils.h"
 
 namespace {
