@@ -27,11 +27,12 @@ constexpr int RS = RW_ + 1;                 // padded LDS row stride
 constexpr int GW = TW + 2, GH = TH + 2;     // 66 x 34 intermediate region
 constexpr int GS = GW + 1;
 
-template <typename T>
-__global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width,
-                                                 int height, uint32_t pattern, int vec_ok) {
-  __shared__ float raw[RHT * RS];
-  __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
+// One 64 x 32 tile.  INTERIOR = the tile, its 1-px intermediate ring and its 4-px raw halo stay at least
+// 3 px inside the image: no in-image tests, no 3x3 border-average path.
+template <typename T, bool INTERIOR>
+__device__ __forceinline__ void ppg_tile(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width, int height,
+                                         uint32_t pattern, int vec_ok, float* __restrict__ raw, float* __restrict__ pr, float* __restrict__ pg,
+                                         float* __restrict__ pb) {
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
 
   {
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, cons
       const int i = threadIdx.x + k * PNT;
       const int r = i / RW_, c = i - r * RW_;
       const int gx = x0 - RH + c, gy = y0 - RH + r;
-      tmp[k] = (i < RW_ * RHT && gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld(src, (size_t)gy * width + gx) : 0.0f;
+      tmp[k] = (i < RW_ * RHT && (INTERIOR || (gx >= 0 && gy >= 0 && gx < width && gy < height))) ? ld(src, (size_t)gy * width + gx) : 0.0f;
     }
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
@@ -61,16 +62,16 @@ __global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, cons
   constexpr int CW = GW / 2, CH = GH / 2;  // 33 x 17 sites per class
   for (int cls = 0; cls < 4; cls++) {
     const int rp = cls >> 1, cp = cls & 1;
+    const int cc = cfa_color(y0 - 1 + rp, x0 - 1 + cp, pattern);  // CFA colour of the whole class (scalar: x0, y0 are even)
     for (int i = threadIdx.x; i < CW * CH; i += PNT) {
       const int rr = i / CW, r = 2 * rr + rp, c = 2 * (i - rr * CW) + cp;
       const int gx = x0 - 1 + c, gy = y0 - 1 + r;
       f3 v = mk3(0.0f, 0.0f, 0.0f);
-      if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
-        if (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3) {
+      if (INTERIOR || (gx >= 0 && gy >= 0 && gx < width && gy < height)) {
+        if (!INTERIOR && (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3)) {
           v = border_average([&](int xx, int yy) { return ld(orig, (size_t)yy * width + xx); }, gx, gy, width, height, pattern);
         } else {
           const float* ctr = raw + (r + RH - 1) * RS + (c + RH - 1);
-          const int cc = cfa_color(gy, gx, pattern);  // the same for every lane (x0, y0 are even)
           const float pc = ctr[0];
           if (cc == 0) v.x = pc;
           else if (cc == 2) v.z = pc;
@@ -99,16 +100,18 @@ __global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, cons
     // waves 0-3 take the even rows, waves 4-7 the odd rows: pixel k of every lane of a wave is the same site class
     const int ly = 2 * ((threadIdx.x >> 4) & 15) + (threadIdx.x >> 8);
     const int x = x0 + lx, y = y0 + ly;
-    if (x >= width || y >= height) return;
+    if (!INTERIOR && (x >= width || y >= height)) return;
+    // this wave's rows all have the parity of y: the site class of pixel k is a scalar
+    const int yu = __builtin_amdgcn_readfirstlane(y);
     float px[12];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int gx = x + k;
       const int base = (ly + 1) * GS + (lx + k + 1);
       f3 col = mk3(pr[base], pg[base], pb[base]);
-      if (gx < width && !(gx == 0 || y == 0 || gx == width - 1 || y == height - 1)) {
+      if (INTERIOR || (gx < width && !(gx == 0 || y == 0 || gx == width - 1 || y == height - 1))) {
         auto nb = [&](int dx, int dy) { const int q = base + dy * GS + dx; return mk3(pr[q], pg[q], pb[q]); };
-        col = ppg_redblue(nb, col, cfa_color(y, gx, pattern), cfa_color(y, gx + 1, pattern) == 0);
+        col = ppg_redblue(nb, col, cfa_color(yu, k, pattern), cfa_color(yu, k + 1, pattern) == 0);  // x0 + lx is a multiple of 4
       }
       px[3 * k] = fmaxf(col.x, 0.0f);
       px[3 * k + 1] = fmaxf(col.y, 0.0f);
@@ -116,6 +119,17 @@ __global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, cons
     }
     store_rgb4(out, x, y, width, vec_ok, px);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, const T* __restrict__ orig, T* __restrict__ out, int width,
+                                                 int height, uint32_t pattern, int vec_ok) {
+  __shared__ float raw[RHT * RS];
+  __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const bool interior = x0 >= 8 && y0 >= 8 && x0 + TW + 8 <= width && y0 + TH + 8 <= height;
+  if (interior) ppg_tile<T, true>(src, orig, out, width, height, pattern, vec_ok, raw, pr, pg, pb);
+  else ppg_tile<T, false>(src, orig, out, width, height, pattern, vec_ok, raw, pr, pg, pb);
 }
 
 // reference ppg.cu:21-113; threshold already divided by 100
