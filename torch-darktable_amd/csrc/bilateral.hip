@@ -8,6 +8,9 @@
 // max(0, L - detail * sigma_r * 4 * trilerp) (:208-228).
 //
 // MI355X design
+//  * small sigma_s (<= 4, the pipeline default 2): the whole op is ONE tile kernel that keeps the grid in
+//    LDS (bilateral_tile_kernel below); the four kernels described next serve larger sigma_s, where the
+//    grid is small, and in-place calls.
 //  * splat: MI355X resolves global float atomics at the memory side (~1.3 TB/s of added bytes
 //    chip-wide) and LDS float atomics cost ~150 cycles per wave instruction, so the reference's
 //    8 atomics/px scatter is turned into a gather: one thread per grid column sums the pixels

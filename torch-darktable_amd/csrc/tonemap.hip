@@ -9,7 +9,8 @@
 //  * statistics: one sample per thread on the stride grid, wave64 __shfl_xor reduction, one LDS
 //    slot per wave, ONE atomic per workgroup and statistic (the reference issues one atomic per
 //    warp per statistic).  The result stays on the device: the normalisation by the valid count
-//    is a 1-thread kernel, not a host .item() (color_adaption.cu:162).
+//    is a 1-thread kernel, not a host .item() (color_adaption.cu:162) -- or, for one image, the
+//    tail of the same launch (tdk_image_metrics: last-workgroup-done, self-cleaning state).
 //  * tonemaps: streaming, four pixels (48 B in, 12 B out) per thread, per-image constants
 //    (map_key, exposure) hoisted out of the pixel loop; dtype-templated input (fp32 / fp16).
 #include <float.h>
