@@ -226,12 +226,11 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
     bool act_a, act_b;
     const T* src_row;
   };
-  auto make_item = [&](int grp_all, int base) {
+  // (plane, gx, gy) of a group are computed once per group (three integer divisions), not per step
+  auto make_item = [&](int plane, int gx, int gy, int base) {
     Item it;
-    const int plane = grp_all / ngroups, grp = grp_all - plane * ngroups;
-    const int gx = grp % ngx, gy = grp / ngx;
     const int jx0 = jmin + gx * GTX, jy = jmin + gy * NW + wave;
-    const bool row_active = (grp_all < total_groups) && (jy < jmin + ntile_y);
+    const bool row_active = jy < jmin + ntile_y;
     it.txa = slot * ov + 2 * base;
     it.txb = it.txa + 1;
     it.act_a = row_active && (jx0 + it.txa < jmin + ntile_x);
@@ -258,7 +257,9 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
 
 
   for (int grp = blockIdx.x; grp < total_groups; grp += gridDim.x) {
-    const float sigma = sigmas[chan + grp / ngroups];
+    const int plane = grp / ngroups, grp_in_plane = grp - plane * ngroups;
+    const int ggy = grp_in_plane / ngx, ggx = grp_in_plane - ggy * ngx;
+    const float sigma = sigmas[chan + plane];
     const float sig2 = sigma * sigma;
     for (int i = lane; i < K * AST / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ im
     // the plain read-modify-writes below never collide.
     for (int base = 0; base < nsteps; base++) {
       float re[K], im[K];
-      const Item it = make_item(grp, base);
+      const Item it = make_item(plane, ggx, ggy, base);
       fetch(it, re, im);
 
       float mean_a, mean_b;
