@@ -92,6 +92,16 @@ int tdk_postprocess(const float* rgb_in, float* rgb_out, void* workspace, int wi
 int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float* gains, int width, int height, uint32_t pattern,
                             tdk_stream_t stream);
 
+/* estimate_white_balance, sample collection: reference csrc/white_balance.cu:57-126 (collect_samples;
+ * extension.cpp:211-212).  One sample per cell of the (height/stride) x (width/stride) grid, n = sh * sw:
+ * chroma[n][2] = (r, g) / (r + g + b), intensity[n] = r + g + b, mask[n] = max(2x2 quad) < 1; the
+ * skipped last row / column of cells (:69) is written as invalid (the reference leaves it
+ * uninitialised).  literal_positions != 0 reads the quad at pos * 2 as the reference does (:71),
+ * 0 reads it at pos * stride (the documented intent).  The quantile / mean (:149-161) are the
+ * binding's device ops, as in the reference.  bayer: (H, W) float32. */
+int tdk_wb_collect_samples(const float* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
+                           float* intensity, uint8_t* mask, tdk_stream_t stream);
+
 /* ---- colour operators: reference csrc/color_conversions.cu (extension.cpp:127-156).
  * (H, W, 3) -> (H, W, 3), npix = H * W. */
 enum tdk_color_op {

@@ -66,7 +66,10 @@ static void border_redblue(float* out, int w, int h, uint32_t pattern, int borde
   free(src);
 }
 
-TDK_API int oracle_rcd(const float* in, float* out, int w, int h, uint32_t pattern) {
+/* dump_pq / dump_p / dump_q (each H*W floats, may be NULL): the lpf_PQ, VP_diff and HQ_diff planes
+ * as they stand after step 4.2, in the reference's flat slot layout -- for the known-answer test of
+ * the idx/2 slot aliasing (tests/test_oracle_kat.py). */
+static int rcd_impl(const float* in, float* out, int w, int h, uint32_t pattern, float* dump_pq, float* dump_p, float* dump_q) {
   if (w & 1) return 1;
   const size_t n = (size_t)w * h;
   float* planes = (float*)calloc(n * 8, sizeof(float));
@@ -169,6 +172,10 @@ TDK_API int oracle_rcd(const float* in, float* out, int w, int h, uint32_t patte
       lpfPQ[idx2] = P_Stat / (P_Stat + Q_Stat);
     }
 
+  if (dump_pq) memcpy(dump_pq, lpfPQ, n * sizeof(float));
+  if (dump_p) memcpy(dump_p, VP, n * sizeof(float));
+  if (dump_q) memcpy(dump_q, HQ, n * sizeof(float));
+
   /* step 5.1 (rcd.cu:185-224): reads and writes rgb0/rgb2 but never the same site class */
 #pragma omp parallel for schedule(static)
   for (int row = 4; row <= h - 4; row++)
@@ -239,4 +246,10 @@ TDK_API int oracle_rcd(const float* in, float* out, int w, int h, uint32_t patte
 
   free(planes);
   return 0;
+}
+
+TDK_API int oracle_rcd(const float* in, float* out, int w, int h, uint32_t pattern) { return rcd_impl(in, out, w, h, pattern, NULL, NULL, NULL); }
+
+TDK_API int oracle_rcd_planes(const float* in, float* out, int w, int h, uint32_t pattern, float* pq, float* p_diff, float* q_diff) {
+  return rcd_impl(in, out, w, h, pattern, pq, p_diff, q_diff);
 }

@@ -132,6 +132,19 @@ def rcd(bayer: np.ndarray, pattern: int) -> np.ndarray:
   return out
 
 
+def rcd_planes(bayer: np.ndarray, pattern: int):
+  """(rgb, PQ_dir plane, p_diff plane, q_diff plane): the three half-density planes as they stand after
+  step 4.2, in the reference's flat `idx / 2` slot layout (H*W floats each, only the first H*W/2 slots used)."""
+  b = _bayer2d(bayer)
+  h, w = b.shape
+  out = np.empty((h, w, 3), np.float32)
+  pq, pd, qd = (np.empty(h * w, np.float32) for _ in range(3))
+  rc = lib().oracle_rcd_planes(_p(b), _p(out), C.c_int(w), C.c_int(h), C.c_uint32(pattern), _p(pq), _p(pd), _p(qd))
+  if rc != 0:
+    raise ValueError('oracle_rcd: width must be even')
+  return out, pq, pd, qd
+
+
 def border_interpolate(bayer: np.ndarray, pattern: int, border: int = 3) -> np.ndarray:
   b = _bayer2d(bayer)
   h, w = b.shape
@@ -167,6 +180,35 @@ def apply_white_balance(bayer: np.ndarray, gains, pattern: int) -> np.ndarray:
   out = np.empty_like(b)
   lib().oracle_apply_white_balance(_p(b), _p(out), C.c_int(w), C.c_int(h), _p(g), C.c_uint32(pattern))
   return out
+
+
+def wb_collect_samples(bayer: np.ndarray, pattern: int, stride: int = 8, literal_positions: bool = False):
+  """(chroma (n, 2), intensity (n,), mask (n,) bool) over the full (H/stride) x (W/stride) cell grid."""
+  b = _f32(bayer)
+  h, w = b.shape
+  n = (h // stride) * (w // stride)
+  chroma, inten, mask = np.empty((n, 2), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
+  lib().oracle_wb_collect_samples(_p(b), C.c_int(w), C.c_int(h), C.c_uint32(pattern), C.c_int(stride), C.c_int(literal_positions), _p(chroma),
+                                  _p(inten), _p(mask))
+  return chroma, inten, mask.astype(bool)
+
+
+def estimate_white_balance(bayer_images, pattern: int, quantile: float = 0.95, stride: int = 8, literal_positions: bool = False) -> np.ndarray:
+  """reference csrc/white_balance.cu:129-161 on top of wb_collect_samples: keep valid samples, select those with
+  intensity >= quantile(intensity, q) (torch.quantile: linear interpolation), mean chroma (mr, mg) ->
+  gains (mr / mg, 1, (1 - mr - mg) / mg); (1, 1, 1) when nothing is valid."""
+  parts = [wb_collect_samples(b, pattern, stride, literal_positions) for b in bayer_images]
+  mask = np.concatenate([p[2] for p in parts])
+  chroma = np.concatenate([p[0] for p in parts])[mask]
+  inten = np.concatenate([p[1] for p in parts])[mask]
+  if chroma.shape[0] == 0:
+    return np.ones(3, np.float32)
+  thr = np.quantile(inten.astype(np.float64), quantile).astype(np.float32)
+  bright = chroma[inten >= thr]
+  if bright.shape[0] == 0:
+    return np.ones(3, np.float32)
+  m = bright.astype(np.float64).mean(0)
+  return np.array([m[0] / m[1], 1.0, (1.0 - m[0] - m[1]) / m[1]], np.float32)
 
 
 # ------------------------------------------------------------------ colour

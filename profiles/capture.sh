@@ -1,0 +1,21 @@
+#!/bin/bash
+# Measurement capture (run on the GPU box from the repo root):
+#   bash profiles/capture.sh <tag> <git-short-hash>
+# Writes everything under gpurun_out/<tag>/; the summaries are then copied into profiles/<tag>/.
+# PMC passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass;
+# SQ has 8 slots per pass).
+set -o pipefail
+TAG=${1:-r02}
+GIT=${2:-unknown}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py --steps 10 --warmup 3 > $OUT/bench_isp_plain.json 2> $OUT/bench_isp_plain.err || exit 1
+python3 bench.py --workload rcd --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rcd_plain.json 2> $OUT/bench_rcd_plain.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_isp_under_rocprof.json 2> $OUT/rocprof_stats.err || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/valu -o v -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_valu.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -o s -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq2.log 2>&1 || echo "sq2 pass failed (optional)"
+python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json $OUT/valu $GIT $OUT/sq2 > $OUT/traffic.log 2>&1 || exit 1
+echo capture done

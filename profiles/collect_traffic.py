@@ -1,27 +1,33 @@
-"""Turns rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950 -- and
-optionally SQ_INSTS_VALU) into profiles/traffic.json: HBM-side bytes per launch for each library
-kernel, plus its vector-ALU instruction count (wave-instructions per launch) under "_valu".
+"""Turns rocprofv3 PMC passes into profiles/traffic.json: per library kernel, HBM-side bytes per launch
+(FETCH_SIZE / WRITE_SIZE -- they do not fit one pass on gfx950), the vector-ALU instruction count
+(wave-instructions per launch) under "_valu", its transcendental part under "_trans", and every SQ
+counter of the passes under "_sq" (means per launch).
 
-On the GPU box:
-  cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/profiles/run_op.py isp --iters 3
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/profiles/run_op.py isp --iters 3
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/valu -- python3 $REPO/profiles/run_op.py isp --iters 3
-  python3 $REPO/profiles/collect_traffic.py $OUT/fetch $OUT/write $REPO/gpurun_out/traffic.json [$OUT/valu]
+On the GPU box (profiles/capture.sh does all of it):
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 profiles/run_op.py isp --iters 3
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE ...   /   --pmc SQ_INSTS_VALU SQ_WAIT_ANY ...
+  python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json [$OUT/valu [GIT_HASH [$OUT/sq2 ...]]]
 
-Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB-like units of
-1024 B... the counters derive from TCC_EA0_RDREQ x 64 B, and on gfx950 a wide coalesced streaming
-read (16 B/lane) is tallied at HALF its bytes, so the read side is doubled for kernels whose loads
-are 16-B vector loads (marked WIDE below); other access widths are reported uncorrected
-(uncalibrated).  WRITE_SIZE needs no correction.  Values are means over the launches seen.
+Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE count in units of 1 KiB; the
+counters derive from TCC_EA0_RDREQ x 64 B, and on gfx950 a wide coalesced streaming read (16 B/lane) is
+tallied at HALF its bytes, so the read side is doubled for kernels whose loads are 16-B (or, calibrated
+below, 8-B) vector streams (marked WIDE); other access widths are reported uncorrected (uncalibrated).
+WRITE_SIZE needs no correction.  Values are means over the launches seen.
+
+Transcendental share: SQ has no per-class VALU counter on gfx950, so the count is the kernel's STATIC share
+of v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos among its VALU instructions (from the code object's
+disassembly, profiles/isa_mix.py) times the measured SQ_INSTS_VALU -- exact for straight-line streaming
+kernels, an estimate for kernels with data-dependent branches.
 """
 import csv
 import glob
 import json
+import subprocess
 import sys
 from collections import defaultdict
+from pathlib import Path
 
-# kernel function name fragment -> (TDK_LAUNCH name used by bench.py, loads are wide 16-B streams)
+# kernel function name fragment -> (TDK_LAUNCH name used by bench.py, loads are wide vector streams)
 KERNELS = {
     'wiener_tiles': ('tdk_wiener(tiles)', True),
     'wiener_finish_modify': ('tdk_wiener(finish+modify)', False),
@@ -43,24 +49,50 @@ KERNELS = {
 }
 
 
-def mean_counter(directory, counter):
+def mean_counters(directory):
+    """{counter: {kernel fragment: mean value per launch}} for every counter found under `directory`."""
     files = glob.glob(f'{directory}/**/*_counter_collection.csv', recursive=True)
-    acc = defaultdict(list)
+    acc = defaultdict(lambda: defaultdict(list))
     for f in files:
         for row in csv.DictReader(open(f)):
-            if row['Counter_Name'] != counter:
-                continue
             for frag in KERNELS:
                 if frag in row['Kernel_Name']:
-                    acc[frag].append(float(row['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                    acc[row['Counter_Name']][frag].append(float(row['Counter_Value']))
+                    break
+    return {c: {k: sum(v) / len(v) for k, v in per.items()} for c, per in acc.items()}
+
+
+def static_trans_share():
+    """{kernel fragment: transcendental share of its static VALU instructions}, via profiles/isa_mix.py."""
+    try:
+        out = subprocess.run([sys.executable, str(Path(__file__).with_name('isa_mix.py')), '--json'], capture_output=True, text=True, timeout=300)
+        mix = json.loads(out.stdout)
+    except Exception:  # noqa: BLE001
+        return {}
+    share = {}
+    for frag in KERNELS:
+        v = t = 0
+        for name, m in mix.items():
+            if frag in name:
+                v += m['valu']
+                t += m['trans']
+        if v:
+            share[frag] = t / v
+    return share
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
-    valu = mean_counter(sys.argv[4], 'SQ_INSTS_VALU') if len(sys.argv) > 4 else {}
-    fetch = mean_counter(fetch_dir, 'FETCH_SIZE')
-    write = mean_counter(write_dir, 'WRITE_SIZE')
+    sq_dirs = [d for i, d in enumerate(sys.argv[4:]) if i != 1]
+    git = sys.argv[5] if len(sys.argv) > 5 else None
+    fetch = mean_counters(fetch_dir).get('FETCH_SIZE', {})
+    write = mean_counters(write_dir).get('WRITE_SIZE', {})
+    sq = {}
+    for d in sq_dirs:
+        for c, per in mean_counters(d).items():
+            sq.setdefault(c, {}).update(per)
+    valu = sq.get('SQ_INSTS_VALU', {})
+    share = static_trans_share()
     result, detail = {}, {}
     for frag, (name, wide) in KERNELS.items():
         if frag not in fetch and frag not in write:
@@ -71,8 +103,10 @@ def main():
         detail[name] = {'FETCH_SIZE_raw': fetch.get(frag), 'WRITE_SIZE_raw': write.get(frag), 'read_bytes': int(rd), 'write_bytes': int(wr),
                         'read_doubled': wide}
     valu_named = {KERNELS[k][0]: int(v) for k, v in valu.items()}
-    json.dump({**result, '_valu': valu_named, '_detail': detail, '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'},
-              open(out, 'w'), indent=1)
+    trans_named = {KERNELS[k][0]: int(v * share[k]) for k, v in valu.items() if k in share}
+    sq_named = {c: {KERNELS[k][0]: round(v, 1) for k, v in per.items()} for c, per in sq.items()}
+    json.dump({**result, '_valu': valu_named, '_trans': trans_named, '_sq': sq_named, '_detail': detail, '_git': git,
+               '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'}, open(out, 'w'), indent=1)
     print(json.dumps(result, indent=1))
 
 

@@ -99,14 +99,71 @@ def test_native_sample_is_preserved(oracle, scene, pat):
         assert np.array_equal(np.take_along_axis(out, ch[:, :, None], 2), bayer)
 
 
-def test_rcd_slot_aliasing_is_reproduced(oracle):
-    """Step 4.2 reads the p/q planes through flat idx/2 slots: for W = 16 the P taps of site
-    (4,4) are (3,3), (4,5), (5,5).  Perturbing exactly one of those CFA
-    neighbourhoods must change the output near (4,4)... checked indirectly: the oracle is a
-    literal flat-index restatement, so here we only pin determinism and the even-width rule."""
-    rng = np.random.default_rng(0)
-    b = rng.uniform(0, 1, (32, 32, 1)).astype(np.float32)
-    assert np.array_equal(oracle.rcd(b, oracle.RGGB), oracle.rcd(b.copy(), oracle.RGGB))
+def _pq_taps(r, c):
+    """P and Q taps of step 4.2 at R/B site (r, c) in 2-D coordinates (derived from the
+    flat `idx / 2` slot arithmetic of rcd.cu:157,173-180 for an even width): an even idx shares its slot with
+    idx + 1 and step 4.1 only writes odd columns, so the three taps are NOT a symmetric diagonal."""
+    if c % 2 == 0:
+        return [(r - 1, c - 1), (r, c + 1), (r + 1, c + 1)], [(r - 1, c + 1), (r, c + 1), (r + 1, c - 1)]
+    return [(r - 1, c), (r, c), (r + 1, c + 2)], [(r - 1, c + 2), (r, c), (r + 1, c)]
+
+
+def _pq_dir_2d(cfa, r, c):
+    """Independent 2-D restatement of steps 4.1 + 4.2 for one site (rcd.cu:149-182), float32, same operation order."""
+    f = np.float32
+
+    def p_diff(y, x):  # NW-SE diagonal high-pass, squared
+        d = (cfa[y - 3, x - 3] - cfa[y - 1, x - 1] - cfa[y + 1, x + 1] + cfa[y + 3, x + 3]) - f(3) * (cfa[y - 2, x - 2] + cfa[y + 2, x + 2]) + f(6) * cfa[y, x]
+        return d * d
+
+    def q_diff(y, x):  # NE-SW diagonal
+        d = (cfa[y - 3, x + 3] - cfa[y - 1, x + 1] - cfa[y + 1, x - 1] + cfa[y + 3, x - 3]) - f(3) * (cfa[y - 2, x + 2] + cfa[y + 2, x - 2]) + f(6) * cfa[y, x]
+        return d * d
+
+    pt, qt = _pq_taps(r, c)
+    P = np.maximum(f(1e-10), p_diff(*pt[0]) + p_diff(*pt[1]) + p_diff(*pt[2]))
+    Q = np.maximum(f(1e-10), q_diff(*qt[0]) + q_diff(*qt[1]) + q_diff(*qt[2]))
+    return P / (P + Q)
+
+
+@pytest.mark.parametrize('W', [16, 24])
+def test_rcd_slot_aliasing_known_answer(oracle, W):
+    """Known-answer test of the one RCD quirk a clean reimplementation would silently 'fix'
+    (rcd.cu:166-182): PQ_dir at an R/B site is built from p/q slots addressed as flat idx / 2.
+    For W = 16, site (4,4): P <- (3,3),(4,5),(5,5), Q <- (3,5),(4,5),(5,3); site (5,5):
+    P <- (4,5),(5,5),(6,7), Q <- (4,7),(5,5),(6,5).  The expected values come from an
+    independent 2-D restatement with those tap tables, not from flat-index code."""
+    H = 20
+    rng = np.random.default_rng(W)
+    cfa = rng.uniform(0.05, 0.95, (H, W)).astype(np.float32)
+    _, pq, _, _ = oracle.rcd_planes(cfa, oracle.RGGB)
+    if W == 16:
+        assert _pq_taps(4, 4) == ([(3, 3), (4, 5), (5, 5)], [(3, 5), (4, 5), (5, 3)])
+        assert _pq_taps(5, 5) == ([(4, 5), (5, 5), (6, 7)], [(4, 7), (5, 5), (6, 5)])
+    checked = 0
+    for r in range(4, H - 4):
+        for c in range(4 + (r & 1), W - 4, 2):  # RGGB: R at even/even, B at odd/odd
+            pt, qt = _pq_taps(r, c)
+            if not all(3 <= y <= H - 4 and 3 <= x <= W - 4 for y, x in pt + qt):
+                continue  # a tap outside step 4.1's write region reads stale v/h_diff (covered by the GPU == oracle tests)
+            assert pq[(r * W + c) // 2] == _pq_dir_2d(cfa, r, c), (r, c)
+            checked += 1
+    assert checked >= 20
+
+    # perturbation: cfa(7,8) lies on the NW-SE diagonal of (4,5) only among the taps of site (4,4) --
+    # PQ_dir(4,4) must move (aliased tap (4,5)); a symmetric P diagonal (3,3),(4,4),(5,5) would not see it
+    bumped = cfa.copy()
+    bumped[7, 8] += np.float32(0.25)
+    _, pq2, _, _ = oracle.rcd_planes(bumped, oracle.RGGB)
+    assert pq2[(4 * W + 4) // 2] != pq[(4 * W + 4) // 2]
+    assert pq2[(4 * W + 4) // 2] == _pq_dir_2d(bumped, 4, 4)
+    # ...cfa(8,8), on the diagonal of tap (5,5), also moves it; cfa(10,2), on none of the six taps' diagonals
+    # (y - x in {0, -1}, y + x in {8, 9} within 3 steps of a tap), does not
+    for (y, x), moves in (((8, 8), True), ((10, 2), False)):
+        b2 = cfa.copy()
+        b2[y, x] += np.float32(0.25)
+        _, pq3, _, _ = oracle.rcd_planes(b2, oracle.RGGB)
+        assert (pq3[(4 * W + 4) // 2] != pq[(4 * W + 4) // 2]) == moves, (y, x)
     with pytest.raises(ValueError):
         oracle.rcd(np.zeros((16, 15, 1), np.float32), oracle.RGGB)
 

@@ -9,19 +9,11 @@
 // pow(x, y) = exp2(y * log2(x)).  Against the libm-based CPU oracle this costs a few 1e-7
 // relative (tests use 2e-5 absolute); the full-accuracy device-library calls are ~20x more
 // instructions and made every colour kernel ALU-bound (0.4 ms instead of ~0.05 ms per 12 MP
-// pass).  Define TDK_PRECISE_MATH to get the device-library versions back.
+// pass).
 #pragma once
 
 #include "tdk_common.h"
 
-#ifdef TDK_PRECISE_MATH
-__device__ __forceinline__ float tdk_pow(float x, float y) { return powf(x, y); }
-__device__ __forceinline__ float tdk_exp(float x) { return expf(x); }
-__device__ __forceinline__ float tdk_log(float x) { return logf(x); }
-__device__ __forceinline__ float tdk_cbrt(float x) { return cbrtf(x); }
-__device__ __forceinline__ float tdk_div(float a, float b) { return a / b; }
-__device__ __forceinline__ float tdk_sqrt(float x) { return sqrtf(x); }
-#else
 // x > 0: exp2(y * log2 x); x == 0: log2 -> -inf -> 0 for y > 0; x < 0 -> NaN (as powf for
 // non-integer y).  pow(x, 0) == 1 including x == 0 is kept by the y == 0 test.
 __device__ __forceinline__ float tdk_pow(float x, float y) {
@@ -35,7 +27,6 @@ __device__ __forceinline__ float tdk_cbrt(float x) { return __builtin_amdgcn_exp
 // sequence is ~10 instructions and the colour kernels carry ~18 divisions per pixel.
 __device__ __forceinline__ float tdk_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float tdk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-#endif
 
 __device__ __forceinline__ f3 clip3(f3 a) { return mk3(clip01(a.x), clip01(a.y), clip01(a.z)); }
 
@@ -57,9 +48,6 @@ __device__ __forceinline__ f3 xyz_to_rgb_lin(f3 v) {
 #define TDK_D65_Y 1.0f
 #define TDK_D65_Z 1.08883f
 
-#ifdef TDK_PRECISE_MATH
-#error "TDK_PRECISE_MATH: restore the literal divisions in namespaces cA / cB before enabling"
-#endif
 namespace cA {  // device_conversions.h
 
 __device__ __forceinline__ float srgb_to_linear(float c) {

@@ -34,6 +34,7 @@ SIGNATURES = {
   'tdk_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
   'tdk_postprocess': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_int, c_float, c_void_p]),
   'tdk_apply_white_balance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_void_p]),
+  'tdk_wb_collect_samples': (c_int, [c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
   'tdk_color_op': (c_int, [c_void_p, c_void_p, c_int64, c_int, C.POINTER(c_float), c_void_p, c_void_p]),
   'tdk_compute_luminance': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
   'tdk_modify_luminance': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -34,7 +34,7 @@ __all__ = [
   'compute_luminance', 'modify_luminance', 'compute_log_luminance', 'modify_log_luminance', 'modify_hsl', 'modify_vibrance',
   'rgb_to_xyz', 'xyz_to_lab', 'lab_to_xyz', 'xyz_to_rgb', 'rgb_to_lab', 'lab_to_rgb', 'color_transform_3x3',
   'compute_image_bounds', 'compute_image_metrics', 'reinhard_tonemap', 'aces_tonemap', 'adaptive_aces_tonemap', 'linear_tonemap',
-  'bilinear5x5_demosaic', 'apply_white_balance', 'estimate_white_balance',
+  'bilinear5x5_demosaic', 'apply_white_balance', 'estimate_white_balance', 'create_wiener',
   'Jpeg', 'JpegException', 'JpegInputFormat', 'JpegSubsampling',
 ]
 
@@ -260,40 +260,39 @@ def apply_white_balance(bayer_image: torch.Tensor, gains: torch.Tensor, pattern)
   return out
 
 
-def estimate_white_balance(bayer_images: Sequence[torch.Tensor], pattern, quantile: float = 0.95, stride: int = 8) -> torch.Tensor:
-  """reference csrc/white_balance.cu:57-161.  Sample extraction is a strided tensor view and the
-  quantile / mean are torch ops on the device, as in the reference (white_balance.cu:149-161).
-  Two reference slips are NOT reproduced: it samples 2x2 cells at
-  `pos * 2` although the grid is sized by `stride`, and leaves skipped mask entries
-  uninitialised; here cell (i, j) is read at (i * stride, j * stride) and every entry is defined."""
+def estimate_white_balance(bayer_images: Sequence[torch.Tensor], pattern, quantile: float = 0.95, stride: int = 8,
+                           literal_positions: bool = False) -> torch.Tensor:
+  """reference csrc/white_balance.cu:57-161.  Sample collection is one HIP kernel per image
+  (tdk_wb_collect_samples); masking, the intensity quantile and the chroma mean are torch ops on
+  the device, as in the reference (white_balance.cu:119-161) -- no host synchronisation except the
+  shape-dependent boolean indexing the reference has too.
+
+  Two reference slips are NOT reproduced by default: it samples 2x2 cells
+  at `pos * 2` although the grid is sized by `stride` (`literal_positions=True` reproduces that
+  read pattern), and it leaves the skipped last row / column of cells uninitialised; here every
+  entry is defined (skipped cells are invalid)."""
   if len(bayer_images) == 0:
     raise RuntimeError('No images provided')
-  pat = BayerPattern(_pattern(pattern))
-  chroma, inten = [], []
-  for img in bayer_images:
-    _require(img.is_cuda and img.dim() == 2, 'bayer images must be CUDA (H, W) tensors')
-    h, w = img.shape
-    sh, sw = h // stride, w // stride
-    ys = torch.arange(sh - 1, device=img.device) * stride
-    xs = torch.arange(sw - 1, device=img.device) * stride
-    p00 = img[ys][:, xs]
-    p01 = img[ys][:, xs + 1]
-    p10 = img[ys + 1][:, xs]
-    p11 = img[ys + 1][:, xs + 1]
-    if pat == BayerPattern.RGGB:
-      r, g, b = p00, (p01 + p10) * 0.5, p11
-    elif pat == BayerPattern.BGGR:
-      r, g, b = p11, (p01 + p10) * 0.5, p00
-    elif pat == BayerPattern.GRBG:
-      r, g, b = p01, (p00 + p11) * 0.5, p10
-    else:
-      r, g, b = p10, (p00 + p11) * 0.5, p01
-    s = r + g + b
-    valid = torch.maximum(torch.maximum(p00, p01), torch.maximum(p10, p11)) < 1.0
-    chroma.append(torch.stack((r / s, g / s), dim=-1)[valid])
-    inten.append(s[valid])
-  chroma_all, inten_all = torch.cat(chroma), torch.cat(inten)
-  dev = bayer_images[0].device
+  pat = _pattern(pattern)
+  stride = int(stride)
+  first = bayer_images[0]
+  _require(first.is_cuda and first.dim() == 2, 'bayer images must be CUDA (H, W) tensors')
+  dev = first.device
+  h, w = first.shape
+  _require(stride >= 2 and h >= stride and w >= stride, 'stride must be >= 2 and not larger than the image')
+  per = (h // stride) * (w // stride)
+  n = per * len(bayer_images)
+  chroma = torch.empty((n, 2), dtype=torch.float32, device=dev)
+  inten = torch.empty(n, dtype=torch.float32, device=dev)
+  mask = torch.empty(n, dtype=torch.bool, device=dev)
+  with torch.cuda.device(dev):
+    for i, img in enumerate(bayer_images):
+      _require(img.is_cuda and img.dim() == 2 and img.dtype == torch.float32, 'bayer images must be float32 CUDA (H, W) tensors')
+      _require(tuple(img.shape) == (h, w) and img.device == dev, 'all bayer images must have the same size and device')
+      x = img.contiguous()
+      check(lib.tdk_wb_collect_samples(_ptr(x), w, h, pat, stride, int(literal_positions), _ptr(chroma[i * per:]), _ptr(inten[i * per:]),
+                                       _ptr(mask[i * per:]), _stream()))
+  chroma_all, inten_all = chroma[mask], inten[mask]
   if chroma_all.size(0) == 0:
     return torch.tensor([1.0, 1.0, 1.0], device=dev)
   bright = chroma_all[inten_all >= torch.quantile(inten_all, quantile)]
@@ -562,6 +561,12 @@ class Wiener(_Workspace):
       check(lib.tdk_wiener_log_luminance(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._tile_size, self._overlap_factor,
                                          _ptr(sig), float(eps), _dtype_tag(x), _stream()))
     return out
+
+
+def create_wiener(device, width: int, height: int, overlap_factor: int = 4, tile_size: int = 32) -> Wiener:
+  """reference torch_darktable_extension.pyi:171-177 (declared there; the reference's extension.cpp never
+  registers it -- its Python helper denoise.create_wiener builds the wrapper class instead)."""
+  return Wiener(device, width, height, overlap_factor, tile_size)
 
 
 # ------------------------------------------------------------------ local contrast
