@@ -48,6 +48,11 @@ __device__ __forceinline__ f3 xyz_to_rgb_lin(f3 v) {
 #define TDK_D65_Y 1.0f
 #define TDK_D65_Z 1.08883f
 
+// The Lab / sRGB / HSL math below may be contracted to FMAs: its transcendentals are hardware approximations
+// already (parity is by tolerance, 2e-5 against the libm oracle), an FMA only removes one rounding, and the
+// 3x3 matrices and a * b + c chains are ~20 % of the colour kernels' instructions.  mat3_mul above (the
+// bit-exact color_transform_3x3) stays uncontracted.
+#pragma clang fp contract(fast)
 namespace cA {  // device_conversions.h
 
 __device__ __forceinline__ float srgb_to_linear(float c) {
@@ -186,3 +191,4 @@ __device__ __forceinline__ f3 vibrance(f3 rgb, float amount) {
 }
 
 }  // namespace cB
+#pragma clang fp contract(off)

@@ -183,6 +183,14 @@ template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst
     else tm = aces_fit(mk3(tdk_div(c.x, ad.x), tdk_div(c.y, ad.y), tdk_div(c.z, ad.z)));
   }
   const f3 g = mk3(tdk_pow(fmaxf(tm.x, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.y, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.z, 0.0f), k.inv_gamma));
+  // modify_rgb_vibrance_dt(g, amount) = clip(lab_to_rgb(scale(rgb_to_lab(g)))) (device_color_conversions.h:199-213).
+  // With amount == 0 both scale factors are exactly 1 and Lab -> RGB inverts RGB -> Lab (no clamp in either, the
+  // two piecewise branches are inverse pairs): the reference's result is clip(g) up to the ~1e-6 round-trip error
+  // of its own fast-math pow / cbrt -- 18 of this kernel's 35 transcendentals per pixel to reproduce a rounding
+  // error that is 2500x below one uint8 step.  The round trip is skipped (wave-uniform branch: `amount` is a
+  // kernel argument); outputs differ from the reference only where its value sits within 1e-6 * 255 of a rounding
+  // tie, the class of difference its own non-deterministic fast-math build already has (test_tonemaps_u8).
+  if (k.vibrance == 0.0f) return clip3(g);
   f3 o = cB::vibrance(g, k.vibrance);
   if constexpr (MODE == TDK_TONEMAP_LINEAR) o = clip3(o);
   return o;

@@ -9,32 +9,52 @@
 // inverse (along y then x, 1/K per pass), (y + mean * wf2d) * wi2d overlap-added, divided by
 // the accumulated wf2d * wi2d mask + 1e-15.
 //
-// MI355X design (memory-side float atomics cap at ~1.3 TB/s, so the reference's ~32 global
-// atomics per pixel cannot be kept; the op is FP32-vector bound: ~2.5 kFLOP/px at ov = 4):
-//  * a wave processes 64/K tiles at once, one tile ROW per lane: the K-point FFTs run entirely
-//    in registers (fully unrolled radix-2 DIT, immediate twiddles, no cross-lane traffic); the
-//    two transposes per direction go through a per-wave padded LDS tile;
-//  * a 512-thread workgroup owns 8 tile rows x (64/K * ov) tile columns (64 x 8s output pixels);
-//    each wave overlap-adds its tile row into a private LDS accumulator with plain 16-B
-//    read-modify-writes -- no atomics anywhere (LDS float atomics are ~150 cycles each);
-//  * each workgroup writes its (64 - s + K) x (7s + K) partial slab once; a second streaming
-//    kernel sums the <= 4 slabs that overlap an output pixel in a fixed order and applies the mask.  The
-//    mask is input-independent and separable (every pixel is covered by exactly ov x ov tiles):
-//    mask(x, y) = m1[x mod s] * m1[y mod s], m1[r] = sum_k wf[r + k s] * wi[r + k s], so it is
-//    never accumulated.
-//  Windows are evaluated on the host in fp64 and rounded once to fp32 (the reference uses torch
-//  fp32 ops on the GPU; both are within an ulp of each other).  This file allows FMA
-//  contraction: the reference's sums are order-nondeterministic, parity is by tolerance.
+// MI355X design.  The op is FP32-vector bound (~2.5 kFLOP/px at ov = 4, against 8-24 B/px), and a wave64
+// VALU instruction holds its wave for 4 cycles but the SIMD-32 for ~2, so the kernel is built around waves per
+// SIMD: 8.4 KB of LDS per wave (the first generation needed 20 KB: 2 waves per SIMD, each 42 % VALU-active).
+//  * a wave carries 64/K "slots" of K lanes; a slot owns one TILE ROW and walks it left to right, two
+//    adjacent tiles (a, b) per step riding ONE complex 2-D FFT (z = a + i b, Hermitian split);
+//  * lane = row of the tile: the K-point FFTs run entirely in registers (tdk_wave_fft.h: radix-2, 6-FMA
+//    butterflies, immediate twiddles); the two transpositions per direction go through a wave-private
+//    (K + 1)-stride LDS buffer, the two slots of a K = 32 wave taking turns in ONE 4.2 KB buffer;
+//  * the frequency -> lane assignment after the transposition puts the Hermitian partner of every bin in
+//    lane ^ 1 (one quad_perm DPP move instead of a ~24-cycle ds_bpermute);
+//  * the overlap-add ALONG x happens in registers: a lane keeps the K - s unfinished columns of its row
+//    (tiles are s apart, so after tiles a, b the first 2 s columns are final for this tile row) -- no LDS
+//    read-modify-write, no atomics (the reference issues ~32 global float atomics per pixel; memory-side
+//    float atomics cap at ~1.3 TB/s on MI355X);
+//  * the overlap-add ACROSS tile rows: the 4 waves of a workgroup (64/K * 4 consecutive tile rows) drop
+//    their 2 s finished columns into their (now free) transposition buffer each step -- the buffers are
+//    double-buffered by step parity, so ONE barrier per step -- and all threads fold the <= ov blocks that
+//    cover an output row in a fixed order and store 16-B pieces to the group's partial slab.  Only the
+//    seams between workgroups (K - s rows / columns) are summed later: a second streaming kernel adds the
+//    <= 4 slabs that overlap a pixel, applies the analytic mask mask(x, y) = m1[x mod s] m1[y mod s],
+//    m1[r] = sum_k wf[r + k s] wi[r + k s] (every pixel is covered by exactly ov x ov tiles, so the mask is
+//    never accumulated), and -- fused -- modify_log_luminance;
+//  * one workgroup per group, G tile columns wide; G is chosen per launch so that the groups fill the
+//    resident workgroup slots of the chip in whole rounds (12 MP: 735 groups on 768 slots).
+//  The whole op is deterministic, unlike the reference's atomic overlap-add.  Windows are evaluated on the
+//  host in fp64 and rounded once to fp32 (the reference uses torch fp32 ops on the GPU; both are within
+//  an ulp of each other).  This file allows FMA contraction: the reference's sums are
+//  order-nondeterministic, parity is by tolerance.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "tdk_color.h"
+#include "tdk_wave_fft.h"
 
 #pragma clang fp contract(fast)
 
 namespace {
 
-constexpr int BS = 64;  // output pixels per workgroup edge = GT * s
+using tdk_fft::fft_inreg;
+using tdk_fft::lane_freq;
+
+constexpr int NWV = 4;  // waves per workgroup of the tile kernel
+#ifndef TDK_WIENER_WAVES_PER_SIMD
+#define TDK_WIENER_WAVES_PER_SIMD 3  // 159 VGPRs, no spills; 4 (128 VGPRs) spills 31 registers and measured 9 % slower
+#endif
 
 struct WParams {
   float wf[32];  // analysis (FFT) window
@@ -42,75 +62,13 @@ struct WParams {
   float m1[16];  // separable mask factor, index p mod s
 };
 
-// cos/sin(2 pi k / 32), k = 0..15 (doubles: the butterflies fold tan / cot from them at compile time)
-constexpr double TW_COS_D[16] = {1.0, 0.98078528040323043, 0.92387953251128674, 0.83146961230254524, 0.70710678118654757,
-                                 0.55557023301960229, 0.38268343236508984, 0.19509032201612833, 0.0, -0.19509032201612819,
-                                 -0.38268343236508973, -0.55557023301960196, -0.70710678118654746, -0.83146961230254535,
-                                 -0.92387953251128674, -0.98078528040323043};
-constexpr double TW_SIN_D[16] = {0.0, 0.19509032201612825, 0.38268343236508978, 0.55557023301960218, 0.70710678118654746,
-                                 0.83146961230254524, 0.92387953251128674, 0.98078528040323043, 1.0, 0.98078528040323043,
-                                 0.92387953251128674, 0.83146961230254546, 0.70710678118654757, 0.55557023301960218,
-                                 0.38268343236508989, 0.19509032201612861};
-
-constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
-constexpr int bitrev(int v, int bits) {
-  int r = 0;
-  for (int b = 0; b < bits; b++) r |= ((v >> b) & 1) << (bits - 1 - b);
-  return r;
-}
-
-// In-register radix-2 decimation-in-time FFT of N complex points (same butterfly network as
-// the reference's shuffle FFT, fft.h:133-167).  Forward: e^{-i...}; inverse: e^{+i...}, UNSCALED
-// (the caller folds the 1/N of each inverse pass into the Wiener gain).
-// A general butterfly a +- w b is written with the twiddle factored as w = c (1 -+ i tan) (or
-// s (cot -+ i) when |c| < |s|): two FMAs form b (1 -+ i tan), four more give both outputs -- 6
-// instructions instead of the 4 multiplies/FMAs + 4 adds of the textbook form.
-template <int N, bool INV> __device__ __forceinline__ void fft_inreg(float (&re)[N], float (&im)[N]) {
-  constexpr int STAGES = ilog2(N);
-#pragma unroll
-  for (int t = 0; t < N; t++) {
-    const int r = bitrev(t, STAGES);
-    if (t < r) {
-      const float a = re[t], b = im[t];
-      re[t] = re[r]; im[t] = im[r];
-      re[r] = a; im[r] = b;
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < STAGES; s++) {
-    const int step = 1 << s;
-#pragma unroll
-    for (int t = 0; t < N; t++) {
-      if ((t & step) == 0) {
-        const int p = t | step;
-        const int k = (t & (step - 1)) * ((N / 2) >> s) * (32 / N);  // index into the 32-point table
-        const float ar = re[t], ai = im[t], br = re[p], bi = im[p];
-        if (k == 0) {            // w = 1
-          re[t] = ar + br; im[t] = ai + bi;
-          re[p] = ar - br; im[p] = ai - bi;
-        } else if (k == 8) {     // w = -i (forward) / +i (inverse)
-          const float xr = INV ? -bi : bi, xi = INV ? br : -br;
-          re[t] = ar + xr; im[t] = ai + xi;
-          re[p] = ar - xr; im[p] = ai - xi;
-        } else {
-          // w = c - i sg (forward), c + i sg (inverse):  w b = (br c + bi sg') + i (bi c - br sg'), sg' = -+sg
-          const double cd = TW_COS_D[k], sd = INV ? -TW_SIN_D[k] : TW_SIN_D[k];
-          if ((cd < 0 ? -cd : cd) >= (sd < 0 ? -sd : sd)) {
-            const float c = (float)cd, tn = (float)(sd / cd);
-            const float pr = __builtin_fmaf(tn, bi, br), pi = __builtin_fmaf(-tn, br, bi);   // b (1 - i tn)
-            re[t] = __builtin_fmaf(c, pr, ar); im[t] = __builtin_fmaf(c, pi, ai);
-            re[p] = __builtin_fmaf(-c, pr, ar); im[p] = __builtin_fmaf(-c, pi, ai);
-          } else {
-            const float sn = (float)sd, ct = (float)(cd / sd);
-            const float pr = __builtin_fmaf(ct, br, bi), pi = __builtin_fmaf(ct, bi, -br);    // b (ct - i)
-            re[t] = __builtin_fmaf(sn, pr, ar); im[t] = __builtin_fmaf(sn, pi, ai);
-            re[p] = __builtin_fmaf(-sn, pr, ar); im[p] = __builtin_fmaf(-sn, pi, ai);
-          }
-        }
-      }
-    }
-  }
-}
+// Slab geometry.  Tile t (0-based, origin index jmin + t) covers padded coordinates u in [t s, t s + K),
+// u = pixel + (ov - 1) s.  A group = TR tile rows x G tile columns; its slab holds the partial sums of
+// u_y in [gy BSY, gy BSY + RSY), u_x in [gx BSX, gx BSX + RSX), row stride RSXP (a multiple of 4 floats).
+struct Geom {
+  int s, K, jmin, ntx, nty, TR, G, ngx, ngy, BSX, BSY, RSX, RSXP, RSY;
+  unsigned magic_x, magic_y;  // ceil(2^32 / BSX), ceil(2^32 / BSY): u / BS == umulhi(u, magic) for u < 2^32 / BS
+};
 
 __device__ __forceinline__ int reflect_index(int x, int limit) {
   if (x < 0) x = -x;
@@ -118,282 +76,312 @@ __device__ __forceinline__ int reflect_index(int x, int limit) {
   return x;
 }
 
-// Transpose one K x K tile held one row per lane through a padded per-wave LDS buffer.  The
-// buffer belongs to one wave (LDS operations of a wave are processed in issue order), so no
-// workgroup barrier is needed -- only a fence that keeps the compiler from reordering.
-template <int K> __device__ __forceinline__ void transpose_tile(float (&v)[K], float* buf, int row) {
-#pragma unroll
-  for (int k = 0; k < K; k++) buf[row * (K + 1) + k] = v[k];
+// x <- (lane is one of the slot's two self-conjugate lanes) ? x : x of lane ^ 1: v_mov_b32_dpp + v_cndmask_b32_e64
+// with the lane mask in an SGPR pair.  (Measured on gfx950, tests/hip_unit/dpp_bench*.hip: the VOP2 form of
+// v_cndmask_b32 -- the only one that takes a DPP operand -- costs ~23 cycles whenever it reads VCC, a
+// ds_bpermute_b32 ~24; v_mov_b32_dpp and the e64 select ~4.5 each.)  Inline asm because hipcc sinks a DPP move
+// into an EXEC-masked branch of the select, where the disabled source lanes read as 0; it inserts no wait
+// states around asm, hence the s_nop (VALU write -> DPP read of the same register needs two).
+__device__ __forceinline__ void partner2(float& a, float& b, unsigned long long self) {
+  float ta, tb;
+  asm volatile("s_nop 1\n\t"
+               "v_mov_b32_dpp %[ta], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mov_b32_dpp %[tb], %[b] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_cndmask_b32_e64 %[a], %[ta], %[a], %[m]\n\t"
+               "v_cndmask_b32_e64 %[b], %[tb], %[b], %[m]"
+               : [a] "+v"(a), [b] "+v"(b), [ta] "=&v"(ta), [tb] "=&v"(tb) : [m] "s"(self));
+}
+
+// Transpose the K x K tile each slot holds one row per lane through a wave-private LDS buffer (LDS operations
+// of one wave execute in issue order, so only compiler fences are needed, no barrier).  K = 16: the four
+// slots of the wave go at once (4 x 16 x 17 floats); K = 32: the two slots take turns in one 32 x 33 buffer --
+// half the footprint, and a half-active wave's ds_read/write_b32 costs half the LDS cycles.  The read side
+// applies the frequency -> lane assignment for free: lane l reads column lane_freq(l).
+__device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int k = 0; k < K; k++) v[k] = buf[k * (K + 1) + row];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 }
-
-// Load K consecutive samples of one tile row (channel `chan` of an HWC image).  Tiles that lie
-// inside the image along x read contiguous memory (16-B vector loads when aligned); only edge
-// tiles pay for the per-sample reflect.
-template <typename T, int K>
-__device__ __forceinline__ void load_row(const T* __restrict__ row_ptr, int ox, int W, int C, int chan, float (&v)[K]) {
-  if (C == 1 && ox >= 0 && ox + K <= W) {
-    const T* p = row_ptr + ox;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+template <int K, bool INV> __device__ __forceinline__ void transpose_lds(float (&v)[K], float* buf, int slot, int row, int col) {
+  constexpr int ST = K + 1;
+  // forward: write [row][k], read [k][col];  inverse: write [k][col], read [row][k]   (col = lane_freq(row))
+  const int wbase = INV ? col : row * ST, rbase = INV ? row * ST : col;
+  constexpr int WS = INV ? ST : 1, RS = INV ? 1 : ST;
+  if constexpr (K == 16) {
+    float* my = buf + slot * (K * ST);
 #pragma unroll
-      for (int k = 0; k < K; k += 4) {
-        float t[4];
-        s4_io<T>::load(p, k / 4, t);
-        v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
+    for (int k = 0; k < K; k++) my[wbase + k * WS] = v[k];
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = my[rbase + k * RS];
+    wave_fence();
+  } else {
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+      if (slot == sl) {
+#pragma unroll
+        for (int k = 0; k < K; k++) buf[wbase + k * WS] = v[k];
       }
-    } else {
+      wave_fence();
+      if (slot == sl) {
 #pragma unroll
-      for (int k = 0; k < K; k++) v[k] = ld(p, k);
+        for (int k = 0; k < K; k++) v[k] = buf[rbase + k * RS];
+      }
+      wave_fence();
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = ld(row_ptr, (size_t)reflect_index(ox + k, W) * C + chan);
   }
 }
 
-// dst[k] += (v[k] + mean * wf[k] wf[ty]) * (wi[k] wi[ty])  (reference denoise.cu:172-175), written as
-// wi[k] * (v[k] * wi[ty] + (mean * wf[ty] wi[ty]) * wf[k]) so that every per-column factor is a scalar
-// (SGPR) operand instead of 64 per-lane registers: 3 instructions per sample.  16-B
-// read-modify-writes when the column offset allows.
-template <int K>
-__device__ __forceinline__ void accumulate_row(float* dst, const float (&v)[K], float mean, float wy, float iy, const WParams& prm, bool vec) {
-  const float mw = mean * (wy * iy);
-  auto term = [&](int k, float a) { return __builtin_fmaf(prm.wi[k], __builtin_fmaf(mw, prm.wf[k], v[k] * iy), a); };
-  if (vec) {
-#pragma unroll
-    for (int k = 0; k < K; k += 4) {
-      float4 a = *reinterpret_cast<float4*>(dst + k);
-      a.x = term(k, a.x); a.y = term(k + 1, a.y); a.z = term(k + 2, a.z); a.w = term(k + 3, a.w);
-      *reinterpret_cast<float4*>(dst + k) = a;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; k++) dst[k] = term(k, dst[k]);
-  }
-}
+// One workgroup = one group: TR = 4 * (64 / K) consecutive tile rows x G tile columns of one plane.
+// NBUF = 2 double-buffers the hand-off block (one barrier per step); 1 when that would not leave room
+// for two workgroups per CU (K = 32, ov = 2: 32 KB per buffer).
+template <typename T, int K, int OV>
+__global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_stream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan, int vec_ok,
+                                                         Geom g, const float* __restrict__ sigmas, WParams prm, int nplanes, size_t plane_stride) {
+  constexpr int S = K / OV, TPW = 64 / K, TR = NWV * TPW;
+  constexpr int EM = 2 * S;      // columns of a tile row that become final per step (tiles a and b)
+  constexpr int CAR = K - S;     // unfinished columns carried to the next step
+  constexpr int WIN = K + S;     // input samples of one step: tile a = w[0, K), tile b = w[S, K + S)
+  constexpr int NQ = EM / 4;     // 16-B pieces per emitted row
+  constexpr int SH = EM >= 32 ? 0 : (EM == 16 ? 1 : (EM == 8 ? 2 : 3));  // rows that share the 32 banks
+  constexpr int FLUSH = (CAR + EM - 1) / EM;
+  // Per-wave LDS region: the transposition buffer during a step, then the wave's EM finished columns for the fold.
+  constexpr int TBUF = (K == 16) ? 4 * 16 * 17 : 32 * 33, EBLK = TPW * K * EM;
+  constexpr int REG = ((TBUF > EBLK ? TBUF : EBLK) + 3) & ~3;
+  constexpr int NBUF = (2 * REG * 4 * 16 <= 160 * 1024) ? 2 : 1;  // two regions (one barrier per step) if 16 waves still fit a CU
+  __shared__ __align__(16) float lds[NBUF * NWV * REG];
 
-constexpr int NW = 8;  // waves per workgroup == tile rows per group
-
-// LDS row stride of a per-wave accumulator: >= n, a multiple of 4 floats with (stride / 4) odd,
-// so the 16-B accesses of 16 lanes on consecutive rows fall in 16 different 4-bank slots.
-__host__ __device__ inline int acc_stride(int n) {
-  int st = (n + 3) & ~3;
-  if (((st >> 2) & 1) == 0) st += 4;
-  return st;
-}
-
-// One workgroup (8 waves) = one group of 8 tile rows x (TPW * ov) tile columns of one channel,
-// i.e. a 64 (x) by 8 s (y) block of output pixels.  Wave w owns tile row w and overlap-adds its
-// tiles into a PRIVATE K-row LDS accumulator with plain 16-B read-modify-writes: the tiles a
-// wave handles at the same time are ov columns apart (they do not overlap) and consecutive tiles
-// are sequential, so no atomics are needed (ds_add_f32 measured ~150 cycles per wave
-// instruction on gfx950 -- it dominated the first version of this kernel).  The eight private
-// accumulators are folded in a fixed order when the group's slab is written: the whole op is
-// deterministic, unlike the reference's atomic overlap-add.
-template <typename T, int K>
-__global__ __launch_bounds__(64 * NW) void wiener_tiles(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan,
-                                                        int s, int ov, int jmin, int ntile_x, int ntile_y, int ngx, int ngroups,
-                                                        const float* __restrict__ sigmas, WParams prm, int nplanes, size_t plane_stride) {
-  constexpr int TPW = 64 / K;  // tile pairs (slots) per wave
-  extern __shared__ __align__(16) float lds[];
-  const int GTX = TPW * ov;
-  const int RSX = BS - s + K, RSY = (NW - 1) * s + K;
-  const int AST = acc_stride(RSX);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per_wave = K * AST + TPW * K * (K + 1);
-  float* acc = lds + wave * per_wave;  // K rows of AST
-  float* tbuf = acc + K * AST;         // per-wave transpose scratch
-  const int row = lane & (K - 1), slot = lane / K;
-  float* my_t = tbuf + slot * (K * (K + 1));
-  // nplanes > 1: `img` holds that many separate planes (C == 1 each, plane_stride samples apart), group
-  // index = plane * ngroups + group, noise sigma = sigmas[chan + plane]
-  const int total_groups = ngroups * nplanes;
-  const int partner = (lane & ~(K - 1)) | ((K - row) & (K - 1));  // lane holding column -kx of the same slot
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = lane / K, row = lane & (K - 1);
+  const int sidx = wave * TPW + slot;  // tile row inside the band
+  const int fcol = (row == 0) ? 0 : (row == 1) ? K / 2 : (row & 1) ? K - (row >> 1) : (row >> 1);  // == lane_freq(row, K)
+  const int ngroups = g.ngx * g.ngy;
+  const int plane = blockIdx.x / ngroups, gin = blockIdx.x - plane * ngroups;
+  const int gy = gin / g.ngx, gx = gin - gy * g.ngx;
+  const int t_row = gy * TR + sidx;
+  const bool row_active = t_row < g.nty;
+  const int jy = g.jmin + t_row;
+  const T* src_row = img + (size_t)plane * plane_stride + (size_t)reflect_index(row_active ? jy * S + row : 0, H) * W * C;
+  const float sigma = sigmas[chan + plane];
+  const float sig2 = sigma * sigma;
   const float wy = prm.wf[row], iy = prm.wi[row];
-  const int nsteps = ov >> 1;
+  // the two self-conjugate lanes (kx = 0 and K/2) of every slot
+  constexpr unsigned long long SELF = (K == 32) ? 0x0000000300000003ull : 0x0003000300030003ull;
+  float* slab = slabs + (size_t)blockIdx.x * (size_t)(g.RSY * g.RSXP);
+  const int steps = g.G >> 1;
 
-  // Work item = (group, step).  Persistent workgroups (one per CU: the LDS footprint allows no
-  // more) walk the groups with a grid stride.  (Fetching the rows of the NEXT item into registers
-  // during the transforms was measured slower: 253 VGPRs, 0.58 vs 0.29 ms.)
-  struct Item {
-    int txa, txb, oxa, oxb;
-    bool act_a, act_b;
-    const T* src_row;
-  };
-  // (plane, gx, gy) of a group are computed once per group (three integer divisions), not per step
-  auto make_item = [&](int plane, int gx, int gy, int base) {
-    Item it;
-    const int jx0 = jmin + gx * GTX, jy = jmin + gy * NW + wave;
-    const bool row_active = jy < jmin + ntile_y;
-    it.txa = slot * ov + 2 * base;
-    it.txb = it.txa + 1;
-    it.act_a = row_active && (jx0 + it.txa < jmin + ntile_x);
-    it.act_b = row_active && (jx0 + it.txb < jmin + ntile_x);
-    it.oxa = (jx0 + it.txa) * s;
-    it.oxb = (jx0 + it.txb) * s;
-    it.src_row = img + (size_t)plane * plane_stride + (size_t)reflect_index(jy * s + row, H) * W * C;
-    return it;
-  };
-  auto fetch = [&](const Item& it, float (&ra)[K], float (&rb)[K]) {
-    if (it.act_a) {
-      load_row<T, K>(it.src_row, it.oxa, W, C, chan, ra);
-    } else {
+  float carry[CAR];
 #pragma unroll
-      for (int k = 0; k < K; k++) ra[k] = 0.0f;
-    }
-    if (it.act_b) {
-      load_row<T, K>(it.src_row, it.oxb, W, C, chan, rb);
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; k++) rb[k] = 0.0f;
-    }
-  };
+  for (int i = 0; i < CAR; i++) carry[i] = 0.0f;
 
-
-  for (int grp = blockIdx.x; grp < total_groups; grp += gridDim.x) {
-    const int plane = grp / ngroups, grp_in_plane = grp - plane * ngroups;
-    const int ggy = grp_in_plane / ngx, ggx = grp_in_plane - ggy * ngx;
-    const float sigma = sigmas[chan + plane];
-    const float sig2 = sigma * sigma;
-    for (int i = lane; i < K * AST / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-
-    // Two real tiles ride through ONE complex 2-D FFT: z = a + i b.  After the forward transform
-    // the spectra are separated with the Hermitian identities A[k] = (Z[k] + conj(Z[-k])) / 2,
-    // B[k] = (Z[k] - conj(Z[-k])) / 2i (Z[-k] sits in lane -kx, register -ky), each gets its own
-    // Wiener gain, and Z' = A' + i B' goes back through one inverse transform: re = a', im = b'.
-    // Tile a / b of slot i in step `base`: columns i*ov + 2*base (+1).  The a (b) tiles of
-    // different slots are ov columns apart, and a and b are accumulated one after the other, so
-    // the plain read-modify-writes below never collide.
-    for (int base = 0; base < nsteps; base++) {
-      float re[K], im[K];
-      const Item it = make_item(plane, ggx, ggy, base);
-      fetch(it, re, im);
-
-      float mean_a, mean_b;
+  for (int m = 0; m < steps + FLUSH; m++) {
+    float S_[WIN];  // sums over this tile row's tiles for columns [2 m S, 2 m S + K + S)
+    if (m < steps) {
+      const int ta = gx * g.G + 2 * m;
+      const bool act_a = row_active && ta < g.ntx, act_b = row_active && ta + 1 < g.ntx;
+      const int ox = (g.jmin + ta) * S;
+      float re[K], im[K], mwa, mwb;
       {
-        float sa = 0.0f, sb = 0.0f;
+        // ---- load the K + S samples of this lane's image row, per-tile means, analysis window
+        float w[WIN];
+        if (vec_ok && C == 1 && ox >= 0 && ox + ((WIN + 3) & ~3) <= W) {
+          const T* p = src_row + ox;
 #pragma unroll
-        for (int k = 0; k < K; k++) { sa += re[k]; sb += im[k]; }
+          for (int k = 0; k + 4 <= WIN; k += 4) {
+            float t4[4];
+            s4_io<T>::load(p, k / 4, t4);
+            w[k] = t4[0]; w[k + 1] = t4[1]; w[k + 2] = t4[2]; w[k + 3] = t4[3];
+          }
+#pragma unroll
+          for (int k = WIN & ~3; k < WIN; k++) w[k] = ld(p, k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < WIN; k++) {
+            const bool need = (k < K) ? act_a : act_b;  // an inactive tile may lie beyond one reflection of the frame
+            w[k] = need ? ld(src_row, (size_t)reflect_index(ox + k, W) * C + chan) : 0.0f;
+          }
+        }
+        if (!act_a) {
+#pragma unroll
+          for (int k = 0; k < K; k++) w[k] = 0.0f;
+        }
+        if (!act_b) {
+#pragma unroll
+          for (int k = K; k < WIN; k++) w[k] = 0.0f;
+        }
+        float sa = 0.0f, sb = 0.0f, head = 0.0f, tail = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; k++) head += w[k];
+#pragma unroll
+        for (int k = S; k < K; k++) sa += w[k];
+#pragma unroll
+        for (int k = K; k < WIN; k++) tail += w[k];
+        sb = act_b ? sa + tail : 0.0f;  // tile b = columns [S, K + S)
+        sa = sa + head;                 // tile a = columns [0, K)
 #pragma unroll
         for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
-        mean_a = sa / (float)(K * K);
-        mean_b = sb / (float)(K * K);
-        const float ca = -mean_a * wy, cb = -mean_b * wy;
+        const float mean_a = sa / (float)(K * K), mean_b = sb / (float)(K * K);
+        const float ca = -mean_a * wy, cb = act_b ? -mean_b * wy : 0.0f;
 #pragma unroll
         for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
-          re[k] = __builtin_fmaf(re[k], wy, ca) * prm.wf[k];
-          im[k] = __builtin_fmaf(im[k], wy, cb) * prm.wf[k];
+          re[k] = __builtin_fmaf(w[k], wy, ca) * prm.wf[k];
+          im[k] = act_b ? __builtin_fmaf(w[k + S], wy, cb) * prm.wf[k] : 0.0f;
         }
+        // mean * wf2d * wi2d is added back after the inverse transform: keep the per-lane factors
+        mwa = mean_a * (wy * iy);
+        mwb = mean_b * (wy * iy);
       }
 
-      fft_inreg<K, false>(re, im);            // along x
-      transpose_tile<K>(re, my_t, row);
-      transpose_tile<K>(im, my_t, row);
-      fft_inreg<K, false>(re, im);            // along y (lane = kx)
+      // ---- forward 2-D FFT of z = a + i b: along x in registers, transpose, along y in registers.
+      // Lane l reads column kx = lane_freq(l) back: the partner bin -kx then sits in lane l ^ 1.
+      float* tbuf = lds + ((NBUF == 2 ? (m & 1) : 0) * NWV + wave) * REG;
+      fft_inreg<K, false>(re, im);
+      transpose_lds<K, false>(re, tbuf, slot, row, fcol);
+      transpose_lds<K, false>(im, tbuf, slot, row, fcol);
+      fft_inreg<K, false>(re, im);  // lane = kx, register = ky
 
-      // Separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  With
-      // 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])):  Z'[k] = ga A + i gb B and, because A
-      // and B are spectra of real tiles, Z'[-k] = ga conj(A) + i gb conj(B) -- the same gains and
-      // products.  Z[-k] lives in the partner lane (column -kx) at register -ky, and the partner
-      // needs exactly the mirrored pair, so every lane evaluates only index ky = k (k = 0..K/2 and
-      // its by-product for the partner's register K-k) and the two lanes swap by-products: half the
-      // gain arithmetic of evaluating every bin.  The 1/2 of A, B and the 1/K^2 of the two
-      // unscaled inverse passes are powers of two folded into the gain (exact).
-      // gain = max(|A|^2 + eps - sigma^2, 0) / (|A|^2 + eps) = max(1 - sigma^2 / p, 0) with p = |A|^2 + eps and
-      // |A|^2 = |2A|^2 / 4: evaluated on p4 = |2A|^2 + 4 eps as max(GS - (4 sigma^2 GS) / p4, 0), GS = the folded
-      // 1/2 * 1/K^2 -- two FMAs for p4, then rcp + FMA + max.
-      constexpr float GSCALE = 0.5f / (float)(K * K);
-      const float sgs = -4.0f * sig2 * GSCALE;
+      // ---- separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  With
+      // 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])):  Z'[k] = ga A + i gb B and, because A and B
+      // are spectra of real tiles, Z'[-k] = ga conj(A) + i gb conj(B) -- the same gains and products.  Z[-k]
+      // lives in the partner lane (column -kx) at register -ky and the partner needs exactly the mirrored
+      // pair, so every lane evaluates only ky = k (k = 0..K/2) plus the by-product for the partner's register
+      // K - k, and the two lanes swap by-products: half the gain arithmetic of evaluating every bin.  The 1/2
+      // of A, B and the 1/K^2 of the two unscaled inverse passes are powers of two folded into the gain.
+      // gain = max(1 - sigma^2 / p, 0) with p = |A|^2 + eps, evaluated on p4 = |2A|^2 + 4 eps as
+      // max(GS - (4 sigma^2 GS) / p4, 0): two FMAs for p4, then rcp + FMA + max.
+      {
+        constexpr float GSCALE = 0.5f / (float)(K * K);
+        const float sgs = -4.0f * sig2 * GSCALE;
 #pragma unroll
-      for (int k = 0; k <= K / 2; k++) {
-        const int k2 = (K - k) & (K - 1);
-        const float zr = re[k], zi = im[k];
-        const float pr = __shfl(re[k2], partner, 64), pi = __shfl(im[k2], partner, 64);  // Z[-k]
-        const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
-        const float pa4 = __builtin_fmaf(a2i, a2i, __builtin_fmaf(a2r, a2r, 4e-15f)), pb4 = __builtin_fmaf(b2i, b2i, __builtin_fmaf(b2r, b2r, 4e-15f));
-        const float ga = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
-        const float gb = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
-        const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
-        re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
-        if (k2 != k) {
-          re[k2] = __shfl(gar + gbi, partner, 64);            // my Z'[K-k] is the partner's by-product
-          im[k2] = __shfl(gbr - gai, partner, 64);
+        for (int k = 0; k <= K / 2; k++) {
+          const int k2 = (K - k) & (K - 1);
+          const float zr = re[k], zi = im[k];
+          float pr = re[k2], pi = im[k2];
+          partner2(pr, pi, SELF);  // Z[-k]
+          const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
+          const float pa4 = __builtin_fmaf(a2i, a2i, __builtin_fmaf(a2r, a2r, 4e-15f)), pb4 = __builtin_fmaf(b2i, b2i, __builtin_fmaf(b2r, b2r, 4e-15f));
+          const float ga = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
+          const float gb = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
+          const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
+          re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
+          if (k2 != k) {
+            float br_ = gar + gbi, bi_ = gbr - gai;             // my Z'[K-k] is the partner's by-product
+            partner2(br_, bi_, SELF);
+            re[k2] = br_; im[k2] = bi_;
+          }
         }
       }
 
-      fft_inreg<K, true>(re, im);             // inverse along y
-      transpose_tile<K>(re, my_t, row);
-      transpose_tile<K>(im, my_t, row);
-      fft_inreg<K, true>(re, im);             // inverse along x (lane = y again): re = tile a, im = tile b
+      // ---- inverse: along y, transpose back (lane = y again, register = kx in natural order), along x
+      fft_inreg<K, true>(re, im);
+      transpose_lds<K, true>(re, tbuf, slot, row, fcol);
+      transpose_lds<K, true>(im, tbuf, slot, row, fcol);
+      fft_inreg<K, true>(re, im);  // re = tile a, im = tile b (row `row` of each)
 
-      if (it.act_a) accumulate_row<K>(acc + row * AST + it.txa * s, re, mean_a, wy, iy, prm, (s & 3) == 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (it.act_b) accumulate_row<K>(acc + row * AST + it.txb * s, im, mean_b, wy, iy, prm, (s & 3) == 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // fold the private accumulators: slab row r gets wave w's row r - w*s for the (at most ov)
-    // waves with 0 <= r - w*s < K, summed in increasing w (s = K / ov is a power of two)
-    float* slab = slabs + (size_t)grp * (size_t)(RSX * RSY);
-    const int ls = 31 - __clz(s);
-    if ((RSX & 3) == 0) {
-      const int QX = RSX >> 2;
-      const float inv_qx = 1.0f / (float)QX;
-      for (int i = threadIdx.x; i < QX * RSY; i += 64 * NW) {
-        const int r = (int)(((float)i + 0.5f) * inv_qx), q = i - r * QX;  // exact: i < 2^20, QX < 2^10
-        const int w_hi = min(r >> ls, NW - 1), w_lo = (r >= K) ? ((r - K) >> ls) + 1 : 0;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int w = w_lo; w <= w_hi; w++) {
-          const float4 a = *reinterpret_cast<const float4*>(lds + w * per_wave + (r - (w << ls)) * AST + 4 * q);
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-        reinterpret_cast<float4*>(slab)[i] = v;
+      // ---- overlap-add along x in registers: (v + mean wf[tx] wf[ty]) * wi[tx] wi[ty]  (denoise.cu:172-175)
+      // written wi[k] * (v * wi[ty] + (mean wf[ty] wi[ty]) * wf[k]): every per-column factor is a scalar operand
+#pragma unroll
+      for (int u = 0; u < WIN; u++) {
+        float acc = (u < CAR) ? carry[u] : 0.0f;
+        if (u < K) acc = __builtin_fmaf(prm.wi[u], __builtin_fmaf(mwa, prm.wf[u], re[u] * iy), acc);
+        if (u >= S) acc = __builtin_fmaf(prm.wi[u - S], __builtin_fmaf(mwb, prm.wf[u - S], im[u - S] * iy), acc);
+        S_[u] = acc;
       }
     } else {
-      const float inv_rsx = 1.0f / (float)RSX;
-      for (int i = threadIdx.x; i < RSX * RSY; i += 64 * NW) {
-        const int r = (int)(((float)i + 0.5f) * inv_rsx), c = i - r * RSX;
-        const int w_hi = min(r >> ls, NW - 1), w_lo = (r >= K) ? ((r - K) >> ls) + 1 : 0;
-        float v = 0.0f;
-        for (int w = w_lo; w <= w_hi; w++) v += lds[w * per_wave + (r - (w << ls)) * AST + c];
-        slab[i] = v;
+      // flush: no more tiles in this group, the carried columns leave as they are (partial sums for the seam)
+#pragma unroll
+      for (int u = 0; u < WIN; u++) S_[u] = (u < CAR) ? carry[u] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < CAR; i++) carry[i] = S_[EM + i];
+
+    // ---- hand the EM finished columns of this tile row to the workgroup: one 16-B piece per quad, XOR-swizzled
+    // so that the 8 lanes of a ds_write_b128 group hit 8 different 4-bank slots
+    float* buf = lds + (NBUF == 2 ? (m & 1) : 0) * (NWV * REG);  // this step's region of wave 0; wave w's is w * REG further
+    {
+      float* dst = buf + wave * REG + (slot * K + row) * EM;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int qs = q ^ ((row >> SH) & (NQ - 1));
+        *reinterpret_cast<float4*>(dst + 4 * qs) = make_float4(S_[4 * q], S_[4 * q + 1], S_[4 * q + 2], S_[4 * q + 3]);
       }
     }
-    __syncthreads();  // the accumulators are zeroed again at the top of the loop
+    __syncthreads();
+    // ---- fold across the band's tile rows: band row r gets tile row sg's row r - sg S for the (at most ov)
+    // tile rows with 0 <= r - sg S < K, summed in increasing sg, and goes to the slab as 16-B pieces
+    {
+      const int col0 = m * EM;
+      for (int i = tid; i < g.RSY * NQ; i += 64 * NWV) {
+        const int r = i / NQ, q = i - r * NQ;
+        if (col0 + 4 * q >= g.RSXP) continue;
+        const int s_hi = min(r / S, TR - 1), s_lo = (r >= K) ? (r - K) / S + 1 : 0;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int sg = s_lo; sg <= s_hi; sg++) {
+          const int lr = r - sg * S;
+          const int qs = q ^ ((lr >> SH) & (NQ - 1));
+          const float4 a = *reinterpret_cast<const float4*>(buf + (sg / TPW) * REG + ((sg % TPW) * K + lr) * EM + 4 * qs);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(slab + (size_t)r * g.RSXP + col0 + 4 * q) = v;
+      }
+    }
+    if (NBUF == 1) __syncthreads();  // single buffer: the fold must finish before the next step overwrites it
   }
+}
+
+// ---------------------------------------------------------------- finish kernels
+// Position of padded coordinate u along one axis: group index, offset inside the group, and whether the
+// previous group's slab also covers it (its last K - s rows / columns).
+struct AxisPos {
+  int grp, off;
+  bool prev;
+};
+__device__ __forceinline__ AxisPos axis_pos(int u, int BS, unsigned magic, int overlap) {
+  AxisPos p;
+  p.grp = (int)__umulhi((unsigned)u, magic);
+  p.off = u - p.grp * BS;
+  p.prev = (p.off < overlap) && p.grp > 0;
+  return p;
+}
+
+// Sum of the <= 4 slabs that cover pixel (x, row): row-level pointers row0 (group row gy) / row1 (group row
+// gy - 1, or null) already include the row offset.
+__device__ __forceinline__ float fold4(const float* __restrict__ row0, const float* __restrict__ row1, int x, int u0, const Geom& g, size_t slab_sz) {
+  const AxisPos px = axis_pos(x + u0, g.BSX, g.magic_x, g.K - g.s);
+  float v = row0[px.grp * slab_sz + px.off];
+  if (px.prev) v += row0[(px.grp - 1) * slab_sz + px.off + g.BSX];
+  if (row1) {
+    v += row1[px.grp * slab_sz + px.off];
+    if (px.prev) v += row1[(px.grp - 1) * slab_sz + px.off + g.BSX];
+  }
+  return v;
+}
+
+struct RowPtrs {
+  const float *row0, *row1;
+  float my;
+};
+__device__ __forceinline__ RowPtrs row_ptrs(const float* __restrict__ slabs, int y, int u0, const Geom& g, size_t slab_sz, const WParams& prm) {
+  const AxisPos py = axis_pos(y + u0, g.BSY, g.magic_y, g.K - g.s);
+  RowPtrs r;
+  r.row0 = slabs + (size_t)py.grp * g.ngx * slab_sz + (size_t)py.off * g.RSXP;
+  r.row1 = py.prev ? slabs + (size_t)(py.grp - 1) * g.ngx * slab_sz + (size_t)(py.off + g.BSY) * g.RSXP : nullptr;
+  r.my = prm.m1[y & (g.s - 1)];
+  return r;
 }
 
 // Sum the overlapping slabs of one channel, normalise by the analytic mask, crop.  One workgroup
-// walks whole image rows (no per-pixel index division; s and BS are powers of two).
+// walks whole image rows.
 template <typename T>
-__global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int C, int chan, int s,
-                                                     int K, int jmin, int ngx, WParams prm) {
-  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
-  const int u0 = -jmin * s;  // = (ov - 1) * s: pixel 0 sits at this offset inside group 0
-  const size_t slab_sz = (size_t)RSX * RSY;
+__global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int C, int chan, Geom g, WParams prm) {
+  const int u0 = -g.jmin * g.s;  // = (ov - 1) * s: pixel 0 sits at this offset inside group 0
+  const size_t slab_sz = (size_t)g.RSXP * g.RSY;
   for (int y = blockIdx.y; y < H; y += gridDim.y) {
-    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
-    const bool py = (offy < K - s) && gy > 0;
-    const float my = prm.m1[y & (s - 1)];
-    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;                   // group row gy
-    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;  // group row gy - 1
+    const RowPtrs rp = row_ptrs(slabs, y, u0, g, slab_sz, prm);
     for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
-      const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
-      const bool px = (offx < K - s) && gx > 0;
-      float v = row0[gx * slab_sz + offx];
-      if (px) v += row0[(gx - 1) * slab_sz + offx + BS];
-      if (py) v += row1[gx * slab_sz + offx];
-      if (px && py) v += row1[(gx - 1) * slab_sz + offx + BS];
-      const float mask = prm.m1[x & (s - 1)] * my;
-      st(out, ((size_t)y * W + x) * C + chan, v / (mask + 1e-15f));
+      const float v = fold4(rp.row0, rp.row1, x, u0, g, slab_sz);
+      const float mask = prm.m1[x & (g.s - 1)] * rp.my;
+      st(out, ((size_t)y * W + x) * C + chan, v * __builtin_amdgcn_rcpf(mask + 1e-15f));  // 1-ulp reciprocal: an IEEE divide is ~20 issue slots
     }
   }
 }
@@ -403,35 +391,25 @@ __global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ s
 // denoised log-luminance plane is never written to HBM.  The colour math must not be contracted.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restrict__ slabs, const T* __restrict__ rgb, T* __restrict__ out, int W, int H,
-                                                            int s, int K, int jmin, int ngx, WParams prm) {
+                                                            Geom g, WParams prm) {
 #pragma clang fp contract(off)
-  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
-  const int u0 = -jmin * s;
-  const size_t slab_sz = (size_t)RSX * RSY;
+  const int u0 = -g.jmin * g.s;
+  const size_t slab_sz = (size_t)g.RSXP * g.RSY;
   const int ngroup = W / VEC;  // VEC == 4 requires W % 4 == 0: a group never straddles a row
   for (int y = blockIdx.y; y < H; y += gridDim.y) {
-    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
-    const bool py = (offy < K - s) && gy > 0;
-    const float my = prm.m1[y & (s - 1)];
-    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;
-    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroup; g += gridDim.x * 256) {
-      const int x0 = g * VEC;
-      const size_t gi = (size_t)y * ngroup + g;
+    const RowPtrs rp = row_ptrs(slabs, y, u0, g, slab_sz, prm);
+    for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
+      const int x0 = gi_ * VEC;
+      const size_t gi = (size_t)y * ngroup + gi_;
       float v[3 * VEC];
       if constexpr (VEC == 4) rgb4_io<T>::load(rgb, gi, v);
       else { v[0] = ld(rgb, gi * 3); v[1] = ld(rgb, gi * 3 + 1); v[2] = ld(rgb, gi * 3 + 2); }
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
         const int x = x0 + k;
-        const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
-        const bool px = (offx < K - s) && gx > 0;
-        float acc = row0[gx * slab_sz + offx];
-        if (px) acc += row0[(gx - 1) * slab_sz + offx + BS];
-        if (py) acc += row1[gx * slab_sz + offx];
-        if (px && py) acc += row1[(gx - 1) * slab_sz + offx + BS];
-        const float mask = prm.m1[x & (s - 1)] * my;
-        const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc / (mask + 1e-15f));
+        const float acc = fold4(rp.row0, rp.row1, x, u0, g, slab_sz);
+        const float mask = prm.m1[x & (g.s - 1)] * rp.my;
+        const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc * __builtin_amdgcn_rcpf(mask + 1e-15f));
         v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
       }
       if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
@@ -462,36 +440,21 @@ __global__ __launch_bounds__(256) void split_planes3(const T* __restrict__ rgb, 
 
 // Finish for three planes at once: fold the slabs of each channel, normalise, write interleaved RGB.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, int s, int K, int jmin, int ngx,
-                                                      int ngroups, WParams prm) {
-  const int RSX = BS - s + K, RSY = (NW - 1) * s + K, BSY = NW * s;
-  const int u0 = -jmin * s;
-  const size_t slab_sz = (size_t)RSX * RSY, chan_sz = slab_sz * ngroups;
+__global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, Geom g, WParams prm) {
+  const int u0 = -g.jmin * g.s;
+  const size_t slab_sz = (size_t)g.RSXP * g.RSY, chan_sz = slab_sz * g.ngx * g.ngy;
   const int ngroup = W / VEC;
   for (int y = blockIdx.y; y < H; y += gridDim.y) {
-    const int uy = y + u0, gy = uy / BSY, offy = uy - gy * BSY;
-    const bool py = (offy < K - s) && gy > 0;
-    const float my = prm.m1[y & (s - 1)];
-    const float* row0 = slabs + (size_t)gy * ngx * slab_sz + (size_t)offy * RSX;
-    const float* row1 = py ? slabs + (size_t)(gy - 1) * ngx * slab_sz + (size_t)(offy + BSY) * RSX : nullptr;
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroup; g += gridDim.x * 256) {
-      const size_t gi = (size_t)y * ngroup + g;
+    const RowPtrs rp = row_ptrs(slabs, y, u0, g, slab_sz, prm);
+    for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
+      const size_t gi = (size_t)y * ngroup + gi_;
       float v[3 * VEC];
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
-        const int x = g * VEC + k;
-        const int ux = x + u0, gx = ux / BS, offx = ux - gx * BS;
-        const bool px = (offx < K - s) && gx > 0;
-        const float norm = prm.m1[x & (s - 1)] * my + 1e-15f;
+        const int x = gi_ * VEC + k;
+        const float rnorm = __builtin_amdgcn_rcpf(prm.m1[x & (g.s - 1)] * rp.my + 1e-15f);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float* r0 = row0 + c * chan_sz;
-          float acc = r0[gx * slab_sz + offx];
-          if (px) acc += r0[(gx - 1) * slab_sz + offx + BS];
-          if (py) acc += row1[c * chan_sz + gx * slab_sz + offx];
-          if (px && py) acc += row1[c * chan_sz + (gx - 1) * slab_sz + offx + BS];
-          v[3 * k + c] = acc / norm;
-        }
+        for (int c = 0; c < 3; c++) v[3 * k + c] = fold4(rp.row0 + c * chan_sz, rp.row1 ? rp.row1 + c * chan_sz : nullptr, x, u0, g, slab_sz) * rnorm;
       }
       if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
       else { st(out, gi * 3, v[0]); st(out, gi * 3 + 1, v[1]); st(out, gi * 3 + 2, v[2]); }
@@ -511,25 +474,69 @@ void make_window(int K, double weight, float* w) {
   for (int i = 0; i < K; i++) w[i] = (float)(v[i] / nrm);
 }
 
-struct Geometry {
-  int s, jmin, ntx, nty, ngx, ngy, RSX, RSY;
-};
+constexpr int G_MIN = 8, G_MAX = 64;  // tile columns per group (even)
 
-Geometry geometry(int W, int H, int K, int ov) {
-  Geometry g;
+// G == 0: the worst case for the workspace size (smallest groups = largest seam overhead).
+Geom geometry(int W, int H, int K, int ov, int G) {
+  Geom g = {};
   g.s = K / ov;
+  g.K = K;
   g.jmin = -(ov - 1);                                  // first origin index whose tile covers pixel 0
   g.ntx = (W - 1) / g.s - g.jmin + 1;                  // origins jmin .. floor((W-1)/s)
   g.nty = (H - 1) / g.s - g.jmin + 1;
-  const int GTX = (64 / K) * ov;                       // == BS / s
-  g.ngx = tdk_div_up(g.ntx, GTX);
-  g.ngy = tdk_div_up(g.nty, NW);
-  g.RSX = BS - g.s + K;
-  g.RSY = (NW - 1) * g.s + K;
+  g.TR = NWV * (64 / K);
+  g.G = G > 0 ? G : G_MIN;
+  g.ngx = tdk_div_up(g.ntx, g.G);
+  g.ngy = tdk_div_up(g.nty, g.TR);
+  g.BSX = g.G * g.s;
+  g.BSY = g.TR * g.s;
+  g.RSX = g.BSX + K - g.s;
+  g.RSXP = (g.RSX + 3) & ~3;
+  g.RSY = g.BSY + K - g.s;
+  g.magic_x = (unsigned)((0x100000000ull + g.BSX - 1) / g.BSX);
+  g.magic_y = (unsigned)((0x100000000ull + g.BSY - 1) / g.BSY);
   return g;
 }
 
-template <int K> WParams make_params(const Geometry& g, int ov) {
+size_t slab_floats(const Geom& g) { return (size_t)g.ngx * g.ngy * g.RSXP * g.RSY; }
+
+int device_cus() {
+  static int cus = 0;  // one device type per process; a stale value only changes the group width, never the result
+  if (cus == 0) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+
+// Group width: the launch is one workgroup per group with `per_cu` workgroups resident per CU, so the run
+// time is ceil(groups / slots) rounds of one group's duration -- pick the width whose last round is
+// fullest (ties: wider groups = fewer seam columns), never using more slab than the workspace (G_MIN) holds.
+int pick_group_width(int W, int H, int K, int ov, int nplanes, int per_cu) {
+  if (const char* e = getenv("TDK_WIENER_G")) {  // experiments only
+    const int G = atoi(e);
+    if (G >= G_MIN && G <= G_MAX && (G & 1) == 0) return G;
+  }
+  const int slots = device_cus() * per_cu;
+  const size_t cap = slab_floats(geometry(W, H, K, ov, 0));
+  int best = G_MIN;
+  double best_eff = -1.0;
+  for (int G = G_MIN; G <= G_MAX; G += 2) {
+    const Geom g = geometry(W, H, K, ov, G);
+    if (slab_floats(g) > cap) continue;
+    const long groups = (long)g.ngx * g.ngy * nplanes;
+    const long rounds = (groups + slots - 1) / slots;
+    // work actually done per round-slot: a group's duration grows with its steps (+ flush rounds)
+    const double steps = G / 2 + (K - g.s + 2 * g.s - 1) / (2 * g.s);
+    const double useful = (double)g.ntx / 2 * g.ngy * nplanes;  // tile-pair steps that carry data
+    const double eff = useful / ((double)rounds * slots * steps);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = G; }
+  }
+  return best;
+}
+
+template <int K> WParams make_params(const Geom& g, int ov) {
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
@@ -541,20 +548,30 @@ template <int K> WParams make_params(const Geometry& g, int ov) {
   return prm;
 }
 
-template <typename T, int K>
-int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, const float* sigmas, const Geometry& g, const WParams& prm, hipStream_t st_,
-                 int nplanes = 1) {
-  constexpr int TPW = 64 / K;
-  const size_t lds_bytes = (size_t)NW * ((size_t)K * acc_stride(g.RSX) + TPW * K * (K + 1)) * sizeof(float);
-  TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&wiener_tiles<T, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
-               "tdk_wiener(hipFuncSetAttribute)");
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int ngroups = g.ngx * g.ngy;
-  const int blocks = ngroups * nplanes < cus ? ngroups * nplanes : cus;  // persistent: one workgroup per CU (LDS-limited), grid-stride over the groups
-  TDK_LAUNCH("tdk_wiener(tiles)", (wiener_tiles<T, K>), dim3(blocks), dim3(64 * NW), lds_bytes, st_, in, slabs, W, H, C, c, g.s, ov, g.jmin, g.ntx,
-             g.nty, g.ngx, ngroups, sigmas, prm, nplanes, (size_t)W * H);
+template <typename T, int K, int OV>
+int launch_tiles_ov(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, const WParams& prm, hipStream_t st_, int nplanes) {
+  const int vec_ok = (C == 1) && tdk_aligned(in, 16) && (W % (16 / (int)sizeof(T)) == 0) && (g.s % (16 / (int)sizeof(T)) == 0);
+  TDK_LAUNCH("tdk_wiener(tiles)", (wiener_stream<T, K, OV>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(64 * NWV), 0, st_, in, slabs, W, H, C, c, vec_ok, g,
+             sigmas, prm, nplanes, (size_t)W * H);
   return TDK_OK;
+}
+
+template <typename T, int K>
+int launch_tiles(const T* in, float* slabs, int W, int H, int C, int c, int ov, const float* sigmas, const Geom& g, const WParams& prm, hipStream_t st_,
+                 int nplanes = 1) {
+  switch (ov) {
+    case 2: return launch_tiles_ov<T, K, 2>(in, slabs, W, H, C, c, sigmas, g, prm, st_, nplanes);
+    case 4: return launch_tiles_ov<T, K, 4>(in, slabs, W, H, C, c, sigmas, g, prm, st_, nplanes);
+    default: return launch_tiles_ov<T, K, 8>(in, slabs, W, H, C, c, sigmas, g, prm, st_, nplanes);
+  }
+}
+
+// workgroups of the tile kernel that fit one CU (LDS: 2 buffers x TR x K x 2s floats, 1 buffer when 2s = 32; 16 waves)
+int tiles_per_cu(int K, int ov) {
+  const int s = K / ov, TR = NWV * (64 / K), em = 2 * s;
+  const int lds = (em >= 32 ? 1 : 2) * TR * K * em * 4;
+  const int by_lds = 160 * 1024 / lds, by_waves = 4 * TDK_WIENER_WAVES_PER_SIMD / NWV;
+  return by_lds < by_waves ? by_lds : by_waves;
 }
 
 inline unsigned stream_blocks(int64_t npix) {
@@ -564,13 +581,13 @@ inline unsigned stream_blocks(int64_t npix) {
 
 template <typename T, int K>
 int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
-  const Geometry g = geometry(W, H, K, ov);
+  const Geom g = geometry(W, H, K, ov, pick_group_width(W, H, K, ov, C == 3 ? 3 : 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   if (C == 3) {
     // de-interleave -> one tile launch over 3 x groups -> one finish that writes whole RGB pixels
-    const size_t slab_floats = (size_t)g.ngx * g.ngy * g.RSX * g.RSY;
-    float* planes = slabs + tdk_align_up(3 * slab_floats, 64);
+    const size_t cap = slab_floats(geometry(W, H, K, ov, 0));
+    float* planes = slabs + tdk_align_up(3 * cap, 64);
     const int64_t npix = (int64_t)W * H;
     const bool vec = (W % 4) == 0 && tdk_aligned(in, 16) && tdk_aligned(out, 16);
     const T* tin = reinterpret_cast<const T*>(in);
@@ -579,15 +596,15 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
     const int rc = launch_tiles<float, K>(planes, slabs, W, H, 1, 0, ov, sigmas, g, prm, st_, 3);
     if (rc != TDK_OK) return rc;
     const dim3 fgrid((unsigned)tdk_div_up(vec ? W / 4 : W, 256), (unsigned)(H < 32768 ? H : 32768));
-    if (vec) TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 4>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g.s, K, g.jmin, g.ngx, g.ngx * g.ngy, prm);
-    else TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 1>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g.s, K, g.jmin, g.ngx, g.ngx * g.ngy, prm);
+    if (vec) TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 4>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g, prm);
+    else TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 1>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g, prm);
     return TDK_OK;
   }
   for (int c = 0; c < C; c++) {
     const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
     if (rc != TDK_OK) return rc;
-    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, C, c, g.s,
-               K, g.jmin, g.ngx, prm);
+    TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
+               reinterpret_cast<T*>(out), W, H, C, c, g, prm);
   }
   return TDK_OK;
 }
@@ -595,20 +612,20 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
 // Wiener.process_log_luminance as one call: extract log-L (fp32 plane in the workspace) -> tiles -> fused fold + modify.
 template <typename T, int K>
 int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_) {
-  const Geometry g = geometry(W, H, K, ov);
+  const Geom g = geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
-  float* plane = slabs + tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY, 64);
+  float* plane = slabs + tdk_align_up(slab_floats(geometry(W, H, K, ov, 0)), 64);
   int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
   if (rc != TDK_OK) return rc;
   rc = launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
   if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16))
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3((unsigned)tdk_div_up(W / 4, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
-               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm);
   else
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 1>), dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
-               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g.s, K, g.jmin, g.ngx, prm);
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm);
   return TDK_OK;
 }
 
@@ -616,11 +633,10 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 
 TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
-  const Geometry g = geometry(width, height, tile_size, overlap_factor);
-  const size_t slab_floats = (size_t)g.ngx * g.ngy * g.RSX * g.RSY;
+  const size_t slabs = slab_floats(geometry(width, height, tile_size, overlap_factor, 0));
   if (channels == 3)  // one slab set per channel + the three de-interleaved fp32 planes
-    return tdk_align_up((tdk_align_up(3 * slab_floats, 64) + 3 * (size_t)width * height) * sizeof(float), 256);
-  return tdk_align_up(slab_floats * sizeof(float), 256);
+    return tdk_align_up((tdk_align_up(3 * slabs, 64) + 3 * (size_t)width * height) * sizeof(float), 256);
+  return tdk_align_up(slabs * sizeof(float), 256);
 }
 
 TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,
@@ -638,10 +654,9 @@ TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width,
 }
 
 TDK_EXPORT size_t tdk_wiener_log_luminance_workspace_bytes(int width, int height, int tile_size, int overlap_factor) {
-  const size_t slabs = tdk_wiener_workspace_bytes(width, height, 1, tile_size, overlap_factor);
-  if (slabs == 0) return 0;
-  const Geometry g = geometry(width, height, tile_size, overlap_factor);
-  return tdk_align_up((tdk_align_up((size_t)g.ngx * g.ngy * g.RSX * g.RSY, 64) + (size_t)width * height) * sizeof(float), 256);
+  if (tdk_wiener_workspace_bytes(width, height, 1, tile_size, overlap_factor) == 0) return 0;
+  const size_t slabs = slab_floats(geometry(width, height, tile_size, overlap_factor, 0));
+  return tdk_align_up((tdk_align_up(slabs, 64) + (size_t)width * height) * sizeof(float), 256);
 }
 
 TDK_EXPORT int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
