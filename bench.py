@@ -205,12 +205,18 @@ def build_pipeline(td, dev, w, h, storage, workload):
     bilateral = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
     params = td.TonemapParameters(gamma=0.75, intensity=2.0, light_adapt=1.0, vibrance=0.0)
 
+    # Stage hand-over of the pipeline package (pipeline/image_processor.py process_rgb; results identical to the
+    # separate wrapper calls, tests/test_gpu_fusion.py): the denoiser also writes the lightness plane of its result,
+    # which Bilateral.process_rgb would extract first.  Per-frame statistics (moving_average = 1) through a
+    # MetricsAccumulator == compute_image_metrics([rgb], stride=8).
+    lum = torch.empty((h, w), dtype=torch.float32, device=dev)
+    acc = td.tonemap.MetricsAccumulator(dev, stride=8)
+
     def frame(bayer):
         rgb = rcd.process(bayer)
-        rgb = wiener.process_log_luminance(rgb, 0.075)
-        rgb = bilateral.process_rgb(rgb, 0.4)
-        metrics = td.compute_image_metrics([rgb], stride=8)  # per-frame statistics (moving_average = 1)
-        return td.reinhard_tonemap(rgb, metrics, params)
+        rgb = wiener.process_log_luminance(rgb, 0.075, luminance_out=lum)
+        rgb = bilateral.process_rgb(rgb, 0.4, luminance=lum, metrics=acc)
+        return td.reinhard_tonemap(rgb, acc.finish(), params)
 
     return dtype, frame
 

@@ -136,10 +136,17 @@ int tdk_image_metrics_init(float* acc, tdk_stream_t stream);
 int tdk_image_metrics_accumulate(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc,
                                  int dtype, tdk_stream_t stream);
 int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream);
-/* One image, one launch: init + accumulate + finish of the three calls above.  `state` is 9 floats
- * of device memory that must be ZERO before the first call; the kernel leaves it zero again, so it
- * can be reused by later calls on the same stream (not concurrently from two streams). */
-int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* state,
+/* The same statistics with a wide accumulator: TDK_METRICS_ACC_FLOATS device floats (TDK_METRICS_SLOTS rows of 8, 16-byte
+ * aligned, ZERO before the first use).  _accumulate_rows adds one image's sums -- one partial per workgroup, spread over
+ * the rows, so the grid is not capped by same-address atomics; _finish_reset sums the rows in a fixed order, writes
+ * metrics[5] normalised by max(valid, 1) and zeroes the accumulator again.  Stream-ordered launches, no in-kernel
+ * "last workgroup" hand-off.  tdk_image_metrics = the two calls for one image. */
+#define TDK_METRICS_SLOTS 1024
+#define TDK_METRICS_ACC_FLOATS (TDK_METRICS_SLOTS * 8)
+int tdk_image_metrics_accumulate_rows(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows,
+                                      int dtype, tdk_stream_t stream);
+int tdk_image_metrics_finish_reset(float* acc_rows, float* metrics, tdk_stream_t stream);
+int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows,
                       float* metrics, int dtype, tdk_stream_t stream);
 
 enum tdk_tonemap { TDK_TONEMAP_REINHARD = 0, TDK_TONEMAP_ACES = 1, TDK_TONEMAP_ACES_ADAPTIVE = 2, TDK_TONEMAP_LINEAR = 3 };
@@ -163,6 +170,14 @@ size_t tdk_wiener_log_luminance_workspace_bytes(int width, int height, int tile_
 int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
                              const float* sigma, float eps, int dtype, tdk_stream_t stream);
 
+/* The same call that ALSO writes the fp32 (H, W) plane compute_luminance(rgb_out) (lum_log_mode 0) or
+ * compute_log_luminance(rgb_out, lum_eps) (1) -- bit for bit what those ops return on the stored result -- for a
+ * consumer that would extract it next: reference torch_darktable/pipeline/image_processor.py:257-271 runs
+ * Wiener.process_log_luminance and then Bilateral.process_rgb, whose first step is that extraction
+ * (local_contrast.py:109-114). */
+int tdk_wiener_log_luminance_lum(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
+                                 const float* sigma, float eps, int dtype, float* lum_out, int lum_log_mode, float lum_eps, tdk_stream_t stream);
+
 /* ---- Bilateral.process: reference csrc/local_contrast/bilateral.cu:358-385 (extension.cpp:111-121) */
 int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]);
 size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
@@ -174,6 +189,11 @@ int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width,
 size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
 int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
                       int log_mode, float eps, int dtype, tdk_stream_t stream);
+
+/* Bilateral.process_rgb / process_log_rgb when the producer of rgb_in already has the fp32 (H, W) plane
+ * compute_[log_]luminance(rgb_in) (tdk_wiener_log_luminance_lum): the extraction pass is skipped, the result is the same. */
+int tdk_bilateral_rgb_lum(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
+                          float sigma_r, float detail, int log_mode, float eps, int dtype, tdk_stream_t stream);
 
 /* ---- Laplacian.process: reference csrc/local_contrast/laplacian.cu:433-480 (extension.cpp:94-108).
  * num_gamma must be 6 (laplacian.cu:625-634). */

@@ -595,14 +595,19 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
 
 template <typename T>
 int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, int log_mode, float eps,
-               int dtype, hipStream_t s) {
+               int dtype, hipStream_t s, const float* lum_in = nullptr) {
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
   const size_t ncell = (size_t)d.sx * d.sy * d.sz;
   float* grid = reinterpret_cast<float*>(workspace);
   float* tmp = grid + tdk_align_up(ncell, 64);
-  float* plane = tmp + tdk_align_up(ncell, 64);
-  int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)width * height, log_mode, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(s));
-  if (rc != TDK_OK) return rc;
+  const float* plane = lum_in;
+  int rc = TDK_OK;
+  if (!plane) {  // the producer of rgb_in did not hand its luminance plane over: extract it
+    float* mine = tmp + tdk_align_up(ncell, 64);
+    rc = tdk_compute_luminance(rgb_in, mine, (int64_t)width * height, log_mode, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(s));
+    if (rc != TDK_OK) return rc;
+    plane = mine;
+  }
   const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
   TileLds L;
   size_t lds_bytes = 0;
@@ -661,5 +666,16 @@ TDK_EXPORT int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* worksp
   TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_rgb: sigmas must be positive");
   TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
   TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, tdk_stream(stream)));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_bilateral_rgb_lum(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
+                                     float sigma_r, float detail, int log_mode, float eps, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb_in && lum_in && rgb_out && workspace, "tdk_bilateral_rgb_lum: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
+  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_rgb_lum: sigmas must be positive");
+  TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
+  TDK_REQUIRE(tdk_aligned(lum_in, 16), "tdk_bilateral_rgb_lum: luminance plane must be 16-byte aligned");
+  TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, tdk_stream(stream), lum_in));
   return TDK_OK;
 }

@@ -86,6 +86,11 @@ template <typename T> __device__ __forceinline__ void st(T* p, size_t i, float v
 template <> __device__ __forceinline__ void st<float>(float* p, size_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st<__half>(__half* p, size_t i, float v) { p[i] = __float2half_rn(v); }
 
+// the value a later kernel will read back after `v` has been stored as T
+template <typename T> __device__ __forceinline__ float as_stored(float v);
+template <> __device__ __forceinline__ float as_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float as_stored<__half>(float v) { return __half2float(__float2half_rn(v)); }
+
 struct f3 {
   float x, y, z;
 };

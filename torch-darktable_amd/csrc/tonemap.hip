@@ -9,8 +9,9 @@
 //  * statistics: one sample per thread on the stride grid, wave64 __shfl_xor reduction, one LDS
 //    slot per wave, ONE atomic per workgroup and statistic (the reference issues one atomic per
 //    warp per statistic).  The result stays on the device: the normalisation by the valid count
-//    is a 1-thread kernel, not a host .item() (color_adaption.cu:162) -- or, for one image, the
-//    tail of the same launch (tdk_image_metrics: last-workgroup-done, self-cleaning state).
+//    is a small kernel, not a host .item() (color_adaption.cu:162).  The wide-accumulator form spreads the
+//    workgroups' partial sums over 1024 rows (same-address float atomics run at ~5 ns each), and its finish
+//    kernel sums the rows and zeroes them again: stream order is the only synchronisation.
 //  * tonemaps: streaming, four pixels (48 B in, 12 B out) per thread, per-image constants
 //    (map_key, exposure) hoisted out of the pixel loop; dtype-templated input (fp32 / fp16).
 #include <float.h>
@@ -77,13 +78,12 @@ __global__ void metrics_init_kernel(float* acc) {
   if (threadIdx.x < 8) acc[threadIdx.x] = 0.0f;
 }
 
-// FUSED: the last workgroup to finish (ticket counter at acc[8]) normalises the sums into
-// `metrics` and zeroes acc[0..8] again, so one launch replaces init + accumulate + finish and the
-// state buffer is ready for the next call.
-template <typename T, bool FUSED>
+// ROWS: the workgroup's partial sums go to row (blockIdx.x mod TDK_METRICS_SLOTS) of a wide accumulator instead of
+// acc[0..5] -- no same-address contention, so the grid can be as wide as the image needs (the single-row form is kept
+// for the three-call API, whose accumulator is 8 floats, and caps its grid at one workgroup per CU).
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
-                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc,
-                                                      float* __restrict__ metrics) {
+                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc) {
   __shared__ float part[4][6];
   const int64_t n = (int64_t)sw * sh;
   const float b0 = bounds[0];
@@ -110,30 +110,9 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
     if ((threadIdx.x & 63) == 0) part[wave][k] = v;
   }
   __syncthreads();
-  const float mine = (threadIdx.x < 6) ? (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]) : 0.0f;
-  if constexpr (!FUSED) {
-    if (threadIdx.x < 6) atomicAdd(&acc[threadIdx.x], mine);
-  } else {
-    // No device-scope fence here: on gfx950 a release fence at agent scope writes the XCD's L2 back
-    // (measured: 3x the whole kernel).  Device-scope atomics are performed at the coherence point;
-    // a RETURNING atomic has been performed once its value is back, so "sums, wait, ticket" in
-    // program order of one wave is enough.
-    __shared__ unsigned int ticket;
-    if (threadIdx.x < 6) {
-      const float old = __hip_atomic_fetch_add(&acc[threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(old));  // keep the returning form
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(acc + 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (ticket == gridDim.x - 1) {  // every other workgroup has added its sums
-      float v = 0.0f;
-      if (threadIdx.x < 6) v = __hip_atomic_exchange(&acc[threadIdx.x], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read and reset
-      const float cnt = __shfl(v, 5, 64);
-      if (threadIdx.x < 5) metrics[threadIdx.x] = v * (1.0f / fmaxf(cnt, 1.0f));  // color_adaption.cu:161-165
-      if (threadIdx.x == 0) __hip_atomic_exchange(reinterpret_cast<unsigned int*>(acc + 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (threadIdx.x < 6) {
+    const float mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    atomicAdd(&acc[(ROWS ? (blockIdx.x & (TDK_METRICS_SLOTS - 1)) * 8 : 0) + threadIdx.x], mine);
   }
 }
 
@@ -142,6 +121,33 @@ __global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __re
   if (threadIdx.x < 5) {
     const float norm = 1.0f / fmaxf(acc[5], 1.0f);
     metrics[threadIdx.x] = acc[threadIdx.x] * norm;
+  }
+}
+
+// finish + self-clean for sums accumulated in TDK_METRICS_SLOTS rows of 8 floats (tdk_bilateral_rgb_fused spreads its
+// workgroups over the rows; tdk_image_metrics_accumulate uses row 0): one workgroup, stream-ordered after the adds;
+// rows are summed in a fixed order.
+__global__ __launch_bounds__(256) void metrics_finish_reset_kernel(float* __restrict__ acc, float* __restrict__ metrics) {
+  __shared__ float part[4][6];
+  float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int r = threadIdx.x; r < TDK_METRICS_SLOTS; r += 256) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) s[k] += acc[r * 8 + k];
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    reinterpret_cast<float4*>(acc + r * 8)[0] = z;
+    reinterpret_cast<float4*>(acc + r * 8)[1] = z;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    const float v = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+    const float cnt = (part[0][5] + part[1][5]) + (part[2][5] + part[3][5]);
+    metrics[k] = v * (1.0f / fmaxf(cnt, 1.0f));  // color_adaption.cu:161-165
   }
 }
 
@@ -315,20 +321,28 @@ TDK_EXPORT int tdk_image_metrics_accumulate(const void* rgb, int width, int heig
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
   const int grid = reduce_grid((int64_t)sw * sh);
   TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", (metrics_kernel<T, false>), dim3(grid), dim3(256), 0, tdk_stream(stream),
-                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc,
-                                                  static_cast<float*>(nullptr)));
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc));
   return TDK_OK;
 }
 
-TDK_EXPORT int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* state,
-                                 float* metrics, int dtype, tdk_stream_t stream) {
-  TDK_REQUIRE(rgb && bounds && state && metrics, "tdk_image_metrics: null pointer");
-  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics: invalid size/stride");
+TDK_EXPORT int tdk_image_metrics_accumulate_rows(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds,
+                                                 float* acc_rows, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb && bounds && acc_rows, "tdk_image_metrics_accumulate_rows: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics_accumulate_rows: invalid size/stride");
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
-  const int grid = reduce_grid((int64_t)sw * sh);
-  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics", (metrics_kernel<T, true>), dim3(grid), dim3(256), 0, tdk_stream(stream),
-                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, state, metrics));
+  // every sample is three scattered loads: latency-bound, so spread it over many workgroups (2 samples per thread)
+  int64_t grid = tdk_div_up64((int64_t)sw * sh, 512);
+  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", (metrics_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, tdk_stream(stream),
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc_rows));
   return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows,
+                                 float* metrics, int dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(metrics, "tdk_image_metrics: null pointer");
+  const int rc = tdk_image_metrics_accumulate_rows(rgb, width, height, stride, min_gray, bounds, acc_rows, dtype, stream);
+  return rc != TDK_OK ? rc : tdk_image_metrics_finish_reset(acc_rows, metrics, stream);
 }
 
 TDK_EXPORT int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream) {
@@ -344,5 +358,12 @@ TDK_EXPORT int tdk_tonemap(const void* rgb, uint8_t* out, int64_t npix, int mode
   TDK_REQUIRE(rgb && out, "tdk_tonemap: null pointer");
   TDK_REQUIRE(mode == TDK_TONEMAP_ACES || metrics != nullptr, "tdk_tonemap: metrics required for this mode");
   TDK_DISPATCH_DTYPE(dtype, T, return dispatch_tonemap<T>(rgb, out, npix, mode, metrics, gamma, intensity, light_adapt, vibrance, tdk_stream(stream)));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_metrics_finish_reset(float* acc, float* metrics, tdk_stream_t stream) {
+  TDK_REQUIRE(acc && metrics, "tdk_image_metrics_finish_reset: null pointer");
+  TDK_REQUIRE(tdk_aligned(acc, 16), "tdk_image_metrics_finish_reset: acc must be 16-byte aligned");
+  TDK_LAUNCH("tdk_image_metrics_finish", metrics_finish_reset_kernel, dim3(1), dim3(256), 0, tdk_stream(stream), acc, metrics);
   return TDK_OK;
 }

@@ -389,9 +389,11 @@ __global__ __launch_bounds__(256) void wiener_finish(const float* __restrict__ s
 // Fused epilogue of Wiener.process_log_luminance (reference denoise.py:54-58): the slab fold and
 // normalisation of wiener_finish followed directly by modify_log_luminance on the RGB pixel, so the
 // denoised log-luminance plane is never written to HBM.  The colour math must not be contracted.
+// lum_out (nullable): also write the fp32 (log-)lightness plane of the pixels as stored -- exactly what
+// compute_[log_]luminance(out) would produce -- for a consumer that extracts it next (Bilateral.process_rgb).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restrict__ slabs, const T* __restrict__ rgb, T* __restrict__ out, int W, int H,
-                                                            Geom g, WParams prm) {
+                                                            Geom g, WParams prm, float* __restrict__ lum_out, int lum_log, float lum_eps) {
 #pragma clang fp contract(off)
   const int u0 = -g.jmin * g.s;
   const size_t slab_sz = (size_t)g.RSXP * g.RSY;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
     for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
       const int x0 = gi_ * VEC;
       const size_t gi = (size_t)y * ngroup + gi_;
-      float v[3 * VEC];
+      float v[3 * VEC], l[VEC];
       if constexpr (VEC == 4) rgb4_io<T>::load(rgb, gi, v);
       else { v[0] = ld(rgb, gi * 3); v[1] = ld(rgb, gi * 3 + 1); v[2] = ld(rgb, gi * 3 + 2); }
 #pragma unroll
@@ -411,9 +413,17 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
         const float mask = prm.m1[x & (g.s - 1)] * rp.my;
         const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc * __builtin_amdgcn_rcpf(mask + 1e-15f));
         v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
+        if (lum_out) {  // wave-uniform; same expression as lum_extract_vec4 (color.hip)
+          const float yv = cA::rgb_to_lab_l(clip3(mk3(as_stored<T>(r.x), as_stored<T>(r.y), as_stored<T>(r.z))));
+          l[k] = lum_log ? tdk_log(fmaxf(lum_eps, yv)) : yv;
+        }
       }
       if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
       else { st(out, gi * 3, v[0]); st(out, gi * 3 + 1, v[1]); st(out, gi * 3 + 2, v[2]); }
+      if (lum_out) {
+        if constexpr (VEC == 4) s4_io<float>::store(lum_out, gi, l);
+        else lum_out[gi] = l[0];
+      }
     }
   }
 }
@@ -611,7 +621,8 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
 
 // Wiener.process_log_luminance as one call: extract log-L (fp32 plane in the workspace) -> tiles -> fused fold + modify.
 template <typename T, int K>
-int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_) {
+int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_,
+                         float* lum_out = nullptr, int lum_log = 0, float lum_eps = 1e-6f) {
   const Geom g = geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
@@ -620,12 +631,12 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
   if (rc != TDK_OK) return rc;
   rc = launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
-  if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16))
+  if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && (!lum_out || tdk_aligned(lum_out, 16)))
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3((unsigned)tdk_div_up(W / 4, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
-               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm);
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm, lum_out, lum_log, lum_eps);
   else
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 1>), dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
-               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm);
+               reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), W, H, g, prm, lum_out, lum_log, lum_eps);
   return TDK_OK;
 }
 
@@ -669,5 +680,19 @@ TDK_EXPORT int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void*
   hipStream_t s = tdk_stream(stream);
   if (tile_size == 16) TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 16>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s)));
   TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 32>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s)));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_wiener_log_luminance_lum(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
+                                            const float* sigma, float eps, int dtype, float* lum_out, int lum_log_mode, float lum_eps, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb_in && rgb_out && workspace && sigma && lum_out, "tdk_wiener_log_luminance_lum: null pointer");
+  TDK_REQUIRE(tile_size == 16 || tile_size == 32, "tile_size must be 16 or 32, got %d", tile_size);
+  TDK_REQUIRE(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8, "overlap_factor must be 2, 4, or 8");
+  TDK_REQUIRE(width >= tile_size && height >= tile_size, "tdk_wiener_log_luminance_lum: image %dx%d smaller than the tile size %d", width, height, tile_size);
+  TDK_REQUIRE(eps > 0.0f && (!lum_log_mode || lum_eps > 0.0f), "Epsilon must be positive");
+  hipStream_t s = tdk_stream(stream);
+  if (tile_size == 16)
+    TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 16>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, lum_log_mode, lum_eps)));
+  TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 32>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, lum_log_mode, lum_eps)));
   return TDK_OK;
 }

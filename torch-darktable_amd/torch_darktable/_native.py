@@ -44,12 +44,16 @@ SIGNATURES = {
   'tdk_image_metrics_init': (c_int, [c_void_p, c_void_p]),
   'tdk_image_metrics_accumulate': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
   'tdk_image_metrics_finish': (c_int, [c_void_p, c_void_p, c_void_p]),
+  'tdk_image_metrics_accumulate_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+  'tdk_image_metrics_finish_reset': (c_int, [c_void_p, c_void_p, c_void_p]),
   'tdk_image_metrics': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
   'tdk_tonemap': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'tdk_wiener_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
   'tdk_wiener': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
   'tdk_wiener_log_luminance_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
   'tdk_wiener_log_luminance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p]),
+  'tdk_wiener_log_luminance_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_int, c_float, c_void_p]),
+  'tdk_bilateral_rgb_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
   'tdk_bilateral_grid_size': (c_int, [c_int, c_int, c_float, c_float, C.POINTER(c_int)]),
   'tdk_bilateral_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),
   'tdk_bilateral': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),

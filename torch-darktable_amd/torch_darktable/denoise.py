@@ -62,12 +62,14 @@ class Wiener:
         lum = extension.compute_luminance(image)
         return extension.modify_luminance(image, self.process(lum.unsqueeze(2), noise).squeeze(2))
 
-    def process_log_luminance(self, image: torch.Tensor, noise, eps: float = 1e-4) -> torch.Tensor:
-        """Denoise the log-lightness of an RGB image (extract -> Wiener -> replace), fused in one library call."""
+    def process_log_luminance(self, image: torch.Tensor, noise, eps: float = 1e-4, *, luminance_out: torch.Tensor | None = None) -> torch.Tensor:
+        """Denoise the log-lightness of an RGB image (extract -> Wiener -> replace), fused in one library call.
+        luminance_out: optional float32 (H, W) tensor that also receives compute_luminance(result), for
+        Bilateral.process_rgb(..., luminance=...) as the next stage."""
         expected = (self._wiener.height, self._wiener.width, 3)
         if tuple(image.shape) != expected:
             raise RuntimeError(f'Wiener input shape {tuple(image.shape)} != expected {expected}')
-        return self._wiener.process_log_luminance(image, self._sigmas(noise, 1), eps)
+        return self._wiener.process_log_luminance(image, self._sigmas(noise, 1), eps, luminance_out)
 
     def process_log(self, image: torch.Tensor, noise, eps: float = 1e-4) -> torch.Tensor:
         return self.process((image + eps).log(), noise).exp()

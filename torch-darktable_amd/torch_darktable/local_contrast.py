@@ -70,12 +70,15 @@ class Bilateral:
         _expect_plane(luminance, self._bilateral, 'Bilateral')
         return self._bilateral.process(luminance, detail)
 
-    def process_rgb(self, input_image: torch.Tensor, detail: float) -> torch.Tensor:
+    def process_rgb(self, input_image: torch.Tensor, detail: float, *, luminance: torch.Tensor | None = None, metrics=None) -> torch.Tensor:
+        """extract -> filter -> replace as one library call.  Optional hand-overs from / to the neighbouring pipeline
+        stages (results unchanged): `luminance` = compute_luminance(input_image) if the producer already has it,
+        `metrics` = a tonemap.MetricsAccumulator that collects compute_image_metrics of the result."""
         assert input_image.dim() == 3, f'image must have 3 dimensions, got {input_image.shape}'
-        return self._bilateral.process_rgb(input_image, float(detail))  # extract -> filter -> replace, one library call
+        return self._bilateral.process_rgb(input_image, float(detail), luminance, metrics)
 
-    def process_log_rgb(self, input_image: torch.Tensor, detail: float, eps: float = 1e-6) -> torch.Tensor:
-        return self._bilateral.process_log_rgb(input_image, float(detail), eps)
+    def process_log_rgb(self, input_image: torch.Tensor, detail: float, eps: float = 1e-6, *, luminance: torch.Tensor | None = None, metrics=None) -> torch.Tensor:
+        return self._bilateral.process_log_rgb(input_image, float(detail), eps, luminance, metrics)
 
     @property
     def image_size(self) -> tuple[int, int]:

@@ -44,6 +44,7 @@ class ImageProcessor:
         self.packed_format = packed_format
         self.transforms = transforms
         self.padding = padding
+        self._lum_plane: torch.Tensor | None = None  # lightness plane handed from the denoiser to the bilateral stage
         self.metrics: torch.Tensor | None = None  # moving averages, device-resident
         self.bounds: torch.Tensor | None = None
         self.rcd_workspace = _debayer.RCD(device, image_size, bayer_pattern)
@@ -136,13 +137,24 @@ class ImageProcessor:
             raise AssertionError(f'Invalid debayer method: {method}')
         return self.postprocess_workspace.process(rgb) if self.settings.postprocess else rgb
 
-    def process_rgb(self, rgb_raw: torch.Tensor, bounds: torch.Tensor | None = None) -> torch.Tensor:
+    def process_rgb(self, rgb_raw: torch.Tensor, bounds: torch.Tensor | None = None, metrics: '_tonemap.MetricsAccumulator | None' = None) -> torch.Tensor:
+        """normalise -> [denoise] -> [local contrast].  When both stages run, the denoiser hands the lightness plane of
+        its result to the bilateral (which would extract it first); with `metrics` the result is also added to that
+        accumulator -- same results as the separate calls."""
         if bounds is not None:
             rgb_raw = normalize_image(rgb_raw, bounds)
-        if self.settings.enable_denoise:
-            rgb_raw = self.wiener_workspace.process_log_luminance(rgb_raw, self.settings.denoise)
-        if self.settings.enable_bilateral:
-            rgb_raw = self.bil_workspace.process_rgb(rgb_raw, self.settings.bilateral)
+        s = self.settings
+        lum = None
+        if s.enable_denoise:
+            if s.enable_bilateral:
+                if self._lum_plane is None or self._lum_plane.device != rgb_raw.device:
+                    self._lum_plane = torch.empty((self.image_size[1], self.image_size[0]), dtype=torch.float32, device=rgb_raw.device)
+                lum = self._lum_plane
+            rgb_raw = self.wiener_workspace.process_log_luminance(rgb_raw, s.denoise, luminance_out=lum)
+        if s.enable_bilateral:
+            rgb_raw = self.bil_workspace.process_rgb(rgb_raw, s.bilateral, luminance=lum, metrics=metrics)
+        elif metrics is not None:
+            metrics.add(rgb_raw)
         return rgb_raw
 
     def tonemap(self, rgb_raw: torch.Tensor, metrics: torch.Tensor | None = None) -> torch.Tensor:
@@ -174,8 +186,9 @@ class ImageProcessor:
         rgb = [self.load_image(b) for b in image_set_bytes.values()]
         bounds = _tonemap.compute_image_bounds(rgb, stride=8)
         self.bounds = lerp(self.bounds if self.bounds is not None else bounds, bounds, ema)
-        rgb = [self.process_rgb(img, self.bounds) for img in rgb]
-        metrics = _tonemap.compute_image_metrics(rgb, stride=8)
+        acc = _tonemap.MetricsAccumulator(self.device, stride=8)  # == compute_image_metrics(rgb, stride=8), fed by the last stage
+        rgb = [self.process_rgb(img, self.bounds, acc) for img in rgb]
+        metrics = acc.finish()
         self.metrics = lerp(self.metrics if self.metrics is not None else metrics, metrics, ema)
         mapped = [self.tonemap(img, self.metrics) for img in rgb]
         return {name: self.transform(img, name) for name, img in zip(names, mapped)}

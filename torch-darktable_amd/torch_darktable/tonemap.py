@@ -82,11 +82,12 @@ def linear_tonemap(image: torch.Tensor, metrics: torch.Tensor, params: TonemapPa
 
 
 compute_image_bounds = extension.compute_image_bounds
+MetricsAccumulator = extension.MetricsAccumulator  # compute_image_metrics in two halves, so producers can feed it (see its docstring)
 
 
 def compute_image_metrics(images: list, stride: int = 8, min_gray: float = 1e-4, rescale: bool = False) -> torch.Tensor:
     return extension.compute_image_metrics(images, stride, min_gray, rescale)
 
 
-__all__ = ['TonemapParameters', 'aces_tonemap', 'compute_image_bounds', 'compute_image_metrics', 'linear_tonemap', 'metrics_from_dict',
+__all__ = ['MetricsAccumulator', 'TonemapParameters', 'aces_tonemap', 'compute_image_bounds', 'compute_image_metrics', 'linear_tonemap', 'metrics_from_dict',
            'metrics_to_dict', 'print_metrics', 'reinhard_tonemap']

@@ -33,7 +33,7 @@ __all__ = [
   'encode12_u16', 'encode12_float', 'decode12_float', 'decode12_half', 'decode12_u16',
   'compute_luminance', 'modify_luminance', 'compute_log_luminance', 'modify_log_luminance', 'modify_hsl', 'modify_vibrance',
   'rgb_to_xyz', 'xyz_to_lab', 'lab_to_xyz', 'xyz_to_rgb', 'rgb_to_lab', 'lab_to_rgb', 'color_transform_3x3',
-  'compute_image_bounds', 'compute_image_metrics', 'reinhard_tonemap', 'aces_tonemap', 'adaptive_aces_tonemap', 'linear_tonemap',
+  'compute_image_bounds', 'compute_image_metrics', 'MetricsAccumulator', 'reinhard_tonemap', 'aces_tonemap', 'adaptive_aces_tonemap', 'linear_tonemap',
   'bilinear5x5_demosaic', 'apply_white_balance', 'estimate_white_balance', 'create_wiener',
   'Jpeg', 'JpegException', 'JpegInputFormat', 'JpegSubsampling',
 ]
@@ -182,6 +182,19 @@ class _Workspace:
 
   def _check_size(self, input: torch.Tensor) -> None:
     _require(input.size(0) == self._height and input.size(1) == self._width, 'Input dimensions must match workspace size')
+
+  def _workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
+    """Cached scratch of at least `nbytes`, one buffer per CUDA stream: a workspace object may be used from
+    several streams (or threads with different current streams) without its kernels sharing slabs / grids."""
+    cache = self.__dict__.setdefault('_scratch', {})
+    key = torch.cuda.current_stream(device).cuda_stream
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+      buf = cache[key] = _workspace(max(int(nbytes), 256), device)
+    return buf
+
+  def _drop_workspaces(self) -> None:
+    self.__dict__.pop('_scratch', None)
 
 
 class PPG(_Workspace):
@@ -455,34 +468,55 @@ def _unit_bounds(dev: torch.device) -> torch.Tensor:
   return _UNIT_BOUNDS[key]
 
 
-def _metrics_state(dev: torch.device) -> torch.Tensor:
-  """Zero-initialised, self-cleaning state of tdk_image_metrics: one per (device, stream)."""
-  key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
-  if key not in _METRICS_STATE:
-    _METRICS_STATE[key] = torch.zeros(16, dtype=torch.float32, device=dev)
-  return _METRICS_STATE[key]
-
-
 def compute_image_metrics(images: Sequence[torch.Tensor], stride: int = 8, min_gray: float = 1e-4, rescale: bool = False) -> torch.Tensor:
   _require(len(images) > 0, 'images must be non-empty')
   dev = images[0].device
   _require(dev.type == 'cuda', 'image must be CUDA')
-  bounds = compute_image_bounds(images, stride) if rescale else _unit_bounds(dev)
-  metrics = torch.empty(5, dtype=torch.float32, device=dev)
-  with torch.cuda.device(dev):
-    if len(images) == 1:  # the per-frame case: one self-cleaning launch instead of init + accumulate + finish
-      x = images[0].contiguous()
-      check(lib.tdk_image_metrics(_ptr(x), x.size(1), x.size(0), int(stride), float(min_gray), _ptr(bounds), _ptr(_metrics_state(dev)),
-                                  _ptr(metrics), _dtype_tag(x), _stream()))
-      return metrics
-    acc = torch.empty(8, dtype=torch.float32, device=dev)
-    check(lib.tdk_image_metrics_init(_ptr(acc), _stream()))
-    for img in images:
-      x = img.contiguous()
-      check(lib.tdk_image_metrics_accumulate(_ptr(x), x.size(1), x.size(0), int(stride), float(min_gray), _ptr(bounds), _ptr(acc),
-                                             _dtype_tag(x), _stream()))
-    check(lib.tdk_image_metrics_finish(_ptr(acc), _ptr(metrics), _stream()))
-  return metrics
+  bounds = compute_image_bounds(images, stride) if rescale else None
+  key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  acc = _METRICS_STATE.get(key)
+  if acc is None:
+    acc = _METRICS_STATE[key] = MetricsAccumulator(dev)
+  acc.stride, acc.min_gray = int(stride), float(min_gray)
+  acc.bounds = bounds if bounds is not None else _unit_bounds(dev)
+  for img in images:
+    acc.add(img)
+  return acc.finish()
+
+
+class MetricsAccumulator:
+  """compute_image_metrics in two halves: `add(image)` accumulates one image's sample-grid sums
+  (tdk_image_metrics_accumulate_rows: a wide accumulator, so the launch is not capped by same-address atomics),
+  `finish()` normalises by the valid-sample count (color_adaption.cu:161-165), returns the 5 metrics on the device
+  and leaves the accumulator zero for the next frame.  Stream order is the only synchronisation.
+  compute_image_metrics(images) == [acc.add(i) for i in images]; acc.finish()."""
+
+  def __init__(self, device, stride: int = 8, min_gray: float = 1e-4, bounds: torch.Tensor | None = None):
+    device = torch.device(device)
+    _require(device.type == 'cuda', 'MetricsAccumulator needs a GPU device')
+    self.stride, self.min_gray = int(stride), float(min_gray)
+    self.bounds = bounds.to(device=device, dtype=torch.float32).contiguous() if bounds is not None else _unit_bounds(device)
+    self.acc = torch.zeros(8192, dtype=torch.float32, device=device)  # TDK_METRICS_ACC_FLOATS: 1024 rows of 8
+
+  def add(self, image: torch.Tensor) -> None:
+    _check_rgb(image, allow_half=True)
+    x = image.contiguous()
+    with torch.cuda.device(x.device):
+      try:
+        check(lib.tdk_image_metrics_accumulate_rows(_ptr(x), x.size(1), x.size(0), self.stride, self.min_gray, _ptr(self.bounds), _ptr(self.acc),
+                                                    _dtype_tag(x), _stream()))
+      except Exception:
+        self.reset()  # never leave half-accumulated sums behind
+        raise
+
+  def finish(self) -> torch.Tensor:
+    metrics = torch.empty(5, dtype=torch.float32, device=self.acc.device)
+    with torch.cuda.device(self.acc.device):
+      check(lib.tdk_image_metrics_finish_reset(_ptr(self.acc), _ptr(metrics), _stream()))
+    return metrics
+
+  def reset(self) -> None:
+    self.acc.zero_()
 
 
 def _tonemap(mode: int, image: torch.Tensor, metrics: torch.Tensor | None, params: TonemapParams) -> torch.Tensor:
@@ -520,7 +554,6 @@ class Wiener(_Workspace):
     super().__init__(device, width, height)
     self._overlap_factor = int(overlap_factor)
     self._tile_size = int(tile_size)
-    self._ws = None
 
   @property
   def overlap_factor(self) -> int:
@@ -538,15 +571,19 @@ class Wiener(_Workspace):
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
       nbytes = lib.tdk_wiener_workspace_bytes(w, h, c, self._tile_size, self._overlap_factor)
-      if self._ws is None or self._ws.numel() < nbytes:
-        self._ws = _workspace(max(nbytes, 256), x.device)
-      check(lib.tdk_wiener(_ptr(x), _ptr(out), _ptr(self._ws), w, h, c, self._tile_size, self._overlap_factor, _ptr(sig), _dtype_tag(x), _stream()))
+      ws = self._workspace(nbytes, x.device)
+      check(lib.tdk_wiener(_ptr(x), _ptr(out), _ptr(ws), w, h, c, self._tile_size, self._overlap_factor, _ptr(sig), _dtype_tag(x), _stream()))
     return out
 
-  def process_log_luminance(self, image: torch.Tensor, noise_sigmas: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+  def process_log_luminance(self, image: torch.Tensor, noise_sigmas: torch.Tensor, eps: float = 1e-4, luminance_out: torch.Tensor | None = None,
+                            luminance_log: bool = False, luminance_eps: float = 1e-6) -> torch.Tensor:
     """Fused form of the reference wrapper's compute_log_luminance -> process -> modify_log_luminance
     (torch_darktable/denoise.py:54-58): one library call, the log-luminance planes stay in fp32
-    scratch and the denoised one is consumed in place."""
+    scratch and the denoised one is consumed in place.
+
+    luminance_out: optional float32 (H, W) tensor that receives compute_luminance(result) (or
+    compute_log_luminance(result, luminance_eps) with luminance_log) -- bit for bit what those ops return -- for a
+    consumer that would extract it next (Bilateral.process_rgb(..., luminance=...))."""
     _check_rgb(image, 'image', allow_half=True)
     _require(image.device == self._device, 'input device mismatch')
     _require(image.size(0) == self._height and image.size(1) == self._width, 'Input dimensions must match workspace size')
@@ -556,10 +593,15 @@ class Wiener(_Workspace):
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
       nbytes = lib.tdk_wiener_log_luminance_workspace_bytes(self._width, self._height, self._tile_size, self._overlap_factor)
-      if self._ws is None or self._ws.numel() < nbytes:
-        self._ws = _workspace(max(nbytes, 256), x.device)
-      check(lib.tdk_wiener_log_luminance(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._tile_size, self._overlap_factor,
-                                         _ptr(sig), float(eps), _dtype_tag(x), _stream()))
+      ws = self._workspace(nbytes, x.device)
+      if luminance_out is None:
+        check(lib.tdk_wiener_log_luminance(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._tile_size, self._overlap_factor,
+                                           _ptr(sig), float(eps), _dtype_tag(x), _stream()))
+      else:
+        _require(luminance_out.dtype == torch.float32 and luminance_out.is_contiguous() and luminance_out.device == x.device
+                 and tuple(luminance_out.shape) == (self._height, self._width), 'luminance_out must be a contiguous float32 (H, W) tensor on the image device')
+        check(lib.tdk_wiener_log_luminance_lum(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._tile_size, self._overlap_factor,
+                                               _ptr(sig), float(eps), _dtype_tag(x), _ptr(luminance_out), int(luminance_log), float(luminance_eps), _stream()))
     return out
 
 
@@ -578,7 +620,6 @@ class Bilateral(_Workspace):
     _require(self._width > 0 and self._height > 0, 'Invalid dimensions')
     self._sigma_s = float(sigma_s)
     self._sigma_r = float(sigma_r)
-    self._ws = None
 
   @property
   def sigma_s(self) -> float:
@@ -587,7 +628,7 @@ class Bilateral(_Workspace):
   @sigma_s.setter
   def sigma_s(self, v: float) -> None:
     self._sigma_s = float(v)
-    self._ws = None
+    self._drop_workspaces()
 
   @property
   def sigma_r(self) -> float:
@@ -596,7 +637,7 @@ class Bilateral(_Workspace):
   @sigma_r.setter
   def sigma_r(self, v: float) -> None:
     self._sigma_r = float(v)
-    self._ws = None
+    self._drop_workspaces()
 
   def grid_size(self) -> tuple[int, int, int]:
     sz = (C.c_int * 3)()
@@ -611,34 +652,44 @@ class Bilateral(_Workspace):
     x = luminance.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      nbytes = lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r)
-      if self._ws is None or self._ws.numel() < nbytes:
-        self._ws = _workspace(nbytes, x.device)
-      check(lib.tdk_bilateral(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+      ws = self._workspace(lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      check(lib.tdk_bilateral(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
                               _dtype_tag(x), _stream()))
     return out
 
-  def _process_rgb(self, image: torch.Tensor, detail: float, log_mode: bool, eps: float) -> torch.Tensor:
+  def _process_rgb(self, image: torch.Tensor, detail: float, log_mode: bool, eps: float, luminance: torch.Tensor | None = None,
+                   metrics: 'MetricsAccumulator | None' = None) -> torch.Tensor:
     _check_rgb(image, 'image', allow_half=True)
     _require(image.size(0) == self._height and image.size(1) == self._width, 'Input shape must match (H,W)')
     x = image.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      nbytes = lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r)
-      if self._ws is None or self._ws.numel() < nbytes:
-        self._ws = _workspace(nbytes, x.device)
-      check(lib.tdk_bilateral_rgb(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
-                                  int(log_mode), float(eps), _dtype_tag(x), _stream()))
+      ws = self._workspace(lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      if luminance is None:
+        check(lib.tdk_bilateral_rgb(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+                                    int(log_mode), float(eps), _dtype_tag(x), _stream()))
+      else:
+        _require(luminance.dtype == torch.float32 and luminance.is_contiguous() and luminance.device == x.device
+                 and tuple(luminance.shape) == (self._height, self._width), 'luminance must be a contiguous float32 (H, W) tensor on the image device')
+        check(lib.tdk_bilateral_rgb_lum(_ptr(x), _ptr(luminance), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r,
+                                        float(detail), int(log_mode), float(eps), _dtype_tag(x), _stream()))
+    if metrics is not None:
+      metrics.add(out)
     return out
 
-  def process_rgb(self, image: torch.Tensor, detail: float) -> torch.Tensor:
-    """Fused compute_luminance -> process -> modify_luminance (reference local_contrast.py:109-114)."""
-    return self._process_rgb(image, detail, False, 1e-6)
+  def process_rgb(self, image: torch.Tensor, detail: float, luminance: torch.Tensor | None = None,
+                  metrics: 'MetricsAccumulator | None' = None) -> torch.Tensor:
+    """Fused compute_luminance -> process -> modify_luminance (reference local_contrast.py:109-114).
+    luminance: the float32 plane compute_luminance(image) if the producer of `image` already has it
+    (Wiener.process_log_luminance(..., luminance_out=...)); metrics: a MetricsAccumulator that is fed the result
+    (the pipeline computes compute_image_metrics of it next)."""
+    return self._process_rgb(image, detail, False, 1e-6, luminance, metrics)
 
-  def process_log_rgb(self, image: torch.Tensor, detail: float, eps: float = 1e-6) -> torch.Tensor:
+  def process_log_rgb(self, image: torch.Tensor, detail: float, eps: float = 1e-6, luminance: torch.Tensor | None = None,
+                      metrics: 'MetricsAccumulator | None' = None) -> torch.Tensor:
     """Fused compute_log_luminance -> process -> modify_log_luminance (reference local_contrast.py:116-125)."""
     _require(eps > 0.0, 'Epsilon must be positive')
-    return self._process_rgb(image, detail, True, eps)
+    return self._process_rgb(image, detail, True, eps, luminance, metrics)
 
 
 class Laplacian(_Workspace):
@@ -654,7 +705,6 @@ class Laplacian(_Workspace):
     self.shadows = float(shadows)
     self.highlights = float(highlights)
     self.clarity = float(clarity)
-    self._ws = None
 
   def process(self, input: torch.Tensor) -> torch.Tensor:
     _require(input.dtype == torch.float32, 'Input tensor must be float32')
@@ -664,9 +714,8 @@ class Laplacian(_Workspace):
     x = input.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      if self._ws is None:
-        self._ws = _workspace(lib.tdk_laplacian_workspace_bytes(self._width, self._height, self._num_gamma), x.device)
-      check(lib.tdk_laplacian(_ptr(x), _ptr(out), _ptr(self._ws), self._width, self._height, self._num_gamma, self.sigma, self.shadows,
+      ws = self._workspace(lib.tdk_laplacian_workspace_bytes(self._width, self._height, self._num_gamma), x.device)
+      check(lib.tdk_laplacian(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._num_gamma, self.sigma, self.shadows,
                               self.highlights, self.clarity, _stream()))
     return out
 
