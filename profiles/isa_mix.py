@@ -18,6 +18,10 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / 'torch-darktable_amd' / 'torch_darktable' / 'libtdk_hip.so'
 LLVM = Path('/opt/rocm/lib/llvm/bin')
 TRANS = re.compile(r'^v_(exp|log|rcp|rsq|sqrt|sin|cos)_')
+# half-rate classes measured on gfx950 (tests/hip_unit/valu_issue_bench.hip): any SGPR / VCC source operand, the 3-input
+# min/max/med forms, conversions to f16
+SGPR_OP = re.compile(r'(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc|exec|m0)(?![\w])')
+HALF3 = re.compile(r'^v_(max3|min3|med3)_')
 
 
 def demangle(names):
@@ -46,7 +50,7 @@ def main():
                 m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
                 if m:
                     cur = m.group(1)
-                    mix[cur] = {'valu': 0, 'trans': 0, 'dpp': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'mfma': 0}
+                    mix[cur] = {'valu': 0, 'trans': 0, 'dpp': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'mfma': 0, 'half': 0, 'cnd_vcc': 0, 'div_fmas': 0}
                     continue
                 if cur is None:
                     continue
@@ -61,6 +65,14 @@ def main():
                     d['valu'] += 1
                     if TRANS.match(op):
                         d['trans'] += 1
+                    elif op.startswith('v_cndmask_b32_e32') or op.startswith('v_cndmask_b32_dpp'):
+                        d['cnd_vcc'] += 1  # VOP2 select reading VCC: ~23 cycles
+                    elif op.startswith('v_div_fmas'):
+                        d['div_fmas'] += 1
+                    else:
+                        srcs = line.strip().split(None, 1)[1].split(',', 1)[1] if ',' in line else ''
+                        if HALF3.match(op) or op.startswith('v_cvt_f16_f32') or SGPR_OP.search(srcs.split('//')[0]):
+                            d['half'] += 1
                     if 'dpp' in line or op.startswith(('v_permlane', 'v_readlane', 'v_writelane', 'v_readfirstlane')):
                         d['dpp'] += 1
                 elif op.startswith('ds_'):
@@ -75,7 +87,10 @@ def main():
         print(json.dumps(mix))
         return
     for k, v in sorted(mix.items(), key=lambda kv: -kv[1]['valu']):
-        print(f"{v['valu']:6d} valu ({v['trans']:4d} trans, {v['dpp']:4d} xlane) {v['salu']:5d} salu {v['lds']:5d} lds {v['vmem']:4d} vmem  {k[:150]}")
+        full = v['valu'] - v['trans'] - v['half'] - v['cnd_vcc'] - v['div_fmas']
+        est = full * 2.4 + v['half'] * 4.8 + v['trans'] * 8.5 + (v['cnd_vcc'] + v['div_fmas']) * 23
+        print(f"{v['valu']:6d} valu ({v['trans']:4d} trans, {v['half']:4d} half-rate, {v['cnd_vcc'] + v['div_fmas']:3d} vcc-read, {v['dpp']:3d} xlane) ~{est:8.0f} issue cyc "
+              f"{v['salu']:5d} salu {v['lds']:5d} lds {v['vmem']:4d} vmem  {k[:110]}")
 
 
 if __name__ == '__main__':

@@ -13,6 +13,9 @@
 #define RCP(i) "v_rcp_f32_e32 %" #i ", %" #i "\n\t"
 #define CND64(i) "v_cndmask_b32_e64 %" #i ", %16, %" #i ", %19\n\t"
 #define MAX3(i) "v_max3_f32 %" #i ", %16, %17, %" #i "\n\t"
+#define MUL_SGPR_E32(i) "v_mul_f32_e32 %" #i ", %18, %" #i "\n\t"
+#define FMAC_SGPR_E32(i) "v_fmac_f32_e32 %" #i ", %18, %16\n\t"
+#define ADD_SGPR_E32(i) "v_add_f32_e32 %" #i ", %18, %" #i "\n\t"
 #define CVT(i) "v_cvt_f16_f32_e32 %" #i ", %" #i "\n\t"
 #define OPERANDS : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) : "v"(x), "v"(y), "s"(sc), "s"(mask)
 template <int MODE> __global__ __launch_bounds__(256) void bench(float* p, int iters) {
@@ -33,6 +36,9 @@ template <int MODE> __global__ __launch_bounds__(256) void bench(float* p, int i
     else if constexpr (MODE == 9) asm volatile(R16(CND64) R16(CND64) OPERANDS);
     else if constexpr (MODE == 10) asm volatile(R16(MAX3) R16(MAX3) OPERANDS);
     else if constexpr (MODE == 11) asm volatile(R16(CVT) R16(CVT) OPERANDS);
+    else if constexpr (MODE == 12) asm volatile(R16(MUL_SGPR_E32) R16(MUL_SGPR_E32) OPERANDS);
+    else if constexpr (MODE == 13) asm volatile(R16(FMAC_SGPR_E32) R16(FMAC_SGPR_E32) OPERANDS);
+    else if constexpr (MODE == 14) asm volatile(R16(ADD_SGPR_E32) R16(ADD_SGPR_E32) OPERANDS);
   }
   float s = 0;
   for (int i = 0; i < 16; i++) s += r[i];
@@ -66,6 +72,9 @@ int main() {
   run<5>("v_mul_f32_e32 literal (8 B)", d);
   run<3>("v_fma_f32 VOP3 vgprs (8 B)", d);
   run<4>("v_fma_f32 VOP3 sgpr (8 B)", d);
+  run<12>("v_mul_f32_e32 sgpr src0 (4 B)", d);
+  run<13>("v_fmac_f32_e32 sgpr src0 (4 B)", d);
+  run<14>("v_add_f32_e32 sgpr src0 (4 B)", d);
   run<10>("v_max3_f32 VOP3 (8 B)", d);
   run<9>("v_cndmask_b32_e64 (8 B)", d);
   run<11>("v_cvt_f16_f32 (4 B)", d);

@@ -56,6 +56,22 @@ constexpr int NWV = 4;  // waves per workgroup of the tile kernel
 #define TDK_WIENER_WAVES_PER_SIMD 3  // 159 VGPRs, no spills; 4 (128 VGPRs) spills 31 registers and measured 9 % slower
 #endif
 
+// The Gaussian analysis / synthesis window (window.h:22-35 with weight 0.3, the only weight the reference uses:
+// denoise.cu:258) as compile-time constants: a VALU instruction with a LITERAL operand issues at full rate on gfx950,
+// one with an SGPR operand (a kernel-argument table) at half rate (tests/hip_unit/valu_issue_bench.hip) -- and the
+// tile kernel multiplies by a window value ~400 times per step.  make_params checks them against make_window().
+template <int K> struct WindowK;
+template <> struct WindowK<16> {
+  static constexpr float w[16] = {0.0227954239f, 0.0472629406f, 0.0882987976f, 0.148644835f, 0.225478873f, 0.308193088f, 0.379577875f, 0.421249986f,
+                                  0.421249986f, 0.379577875f, 0.308193088f, 0.225478873f, 0.148644835f, 0.0882987976f, 0.0472629406f, 0.0227954239f};
+};
+template <> struct WindowK<32> {
+  static constexpr float w[32] = {0.0132160187f, 0.01953201f, 0.0281244125f, 0.0394557454f, 0.0539296083f, 0.0718182027f, 0.093182005f, 0.117793098f,
+                                  0.145076767f, 0.174086913f, 0.203528211f, 0.231831998f, 0.257283777f, 0.278190076f, 0.293063104f, 0.300795197f,
+                                  0.300795197f, 0.293063104f, 0.278190076f, 0.257283777f, 0.231831998f, 0.203528211f, 0.174086913f, 0.145076767f,
+                                  0.117793098f, 0.093182005f, 0.0718182027f, 0.0539296083f, 0.0394557454f, 0.0281244125f, 0.01953201f, 0.0132160187f};
+};
+
 struct WParams {
   float wf[32];  // analysis (FFT) window
   float wi[32];  // synthesis (interpolation) window
@@ -221,11 +237,12 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
 #pragma unroll
         for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
         const float mean_a = sa / (float)(K * K), mean_b = sb / (float)(K * K);
-        const float ca = -mean_a * wy, cb = act_b ? -mean_b * wy : 0.0f;
+        const float wyb = act_b ? wy : 0.0f;  // tile b absent: its row factor is 0 (one select instead of K)
+        const float ca = -mean_a * wy, cb = -mean_b * wyb;
 #pragma unroll
-        for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor stays a scalar operand
-          re[k] = __builtin_fmaf(w[k], wy, ca) * prm.wf[k];
-          im[k] = act_b ? __builtin_fmaf(w[k + S], wy, cb) * prm.wf[k] : 0.0f;
+        for (int k = 0; k < K; k++) {  // (x - mean) * wf[ty] * wf[tx]; the per-column factor is a literal
+          re[k] = __builtin_fmaf(w[k], wy, ca) * WindowK<K>::w[k];
+          im[k] = __builtin_fmaf(w[k + S], wyb, cb) * WindowK<K>::w[k];
         }
         // mean * wf2d * wi2d is added back after the inverse transform: keep the per-lane factors
         mwa = mean_a * (wy * iy);
@@ -251,7 +268,8 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
       // max(GS - (4 sigma^2 GS) / p4, 0): two FMAs for p4, then rcp + FMA + max.
       {
         constexpr float GSCALE = 0.5f / (float)(K * K);
-        const float sgs = -4.0f * sig2 * GSCALE;
+        float sgs = -4.0f * sig2 * GSCALE;
+        asm volatile("" : "+v"(sgs));  // keep it in a VGPR: a VALU instruction with an SGPR operand issues at half rate
 #pragma unroll
         for (int k = 0; k <= K / 2; k++) {
           const int k2 = (K - k) & (K - 1);
@@ -283,8 +301,8 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
 #pragma unroll
       for (int u = 0; u < WIN; u++) {
         float acc = (u < CAR) ? carry[u] : 0.0f;
-        if (u < K) acc = __builtin_fmaf(prm.wi[u], __builtin_fmaf(mwa, prm.wf[u], re[u] * iy), acc);
-        if (u >= S) acc = __builtin_fmaf(prm.wi[u - S], __builtin_fmaf(mwb, prm.wf[u - S], im[u - S] * iy), acc);
+        if (u < K) acc = __builtin_fmaf(WindowK<K>::w[u], __builtin_fmaf(mwa, WindowK<K>::w[u], re[u] * iy), acc);
+        if (u >= S) acc = __builtin_fmaf(WindowK<K>::w[u - S], __builtin_fmaf(mwb, WindowK<K>::w[u - S], im[u - S] * iy), acc);
         S_[u] = acc;
       }
     } else {
@@ -550,6 +568,8 @@ template <int K> WParams make_params(const Geom& g, int ov) {
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
+  for (int i = 0; i < K; i++)
+    if (prm.wf[i] != WindowK<K>::w[i] || prm.wi[i] != WindowK<K>::w[i]) abort();  // the compiled-in table no longer matches make_window()
   for (int r = 0; r < g.s; r++) {
     float m = 0.0f;
     for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
