@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--width', type=int, default=4096)
     ap.add_argument('--height', type=int, default=3072)
-    ap.add_argument('--only', default='', help='substring filter on op names')
+    ap.add_argument('--only', default='', help='substring filter on op names (several: a|b)')
     a = ap.parse_args()
     import torch_darktable as td
     from torch_darktable import _native
@@ -99,7 +99,7 @@ def main():
 
     rows = []
     for name, (fn, nbytes) in ops.items():
-        if a.only and a.only.lower() not in name.lower():
+        if a.only and not any(t.strip().lower() in name.lower() for t in a.only.split('|')):
             continue
         try:
             fn()

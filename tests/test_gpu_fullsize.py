@@ -114,9 +114,13 @@ def test_bilateral_12mp(td, oracle, dev, frame12):
 
 
 def test_full_pipeline_12mp_fp16_vs_fp32_oracle(td, oracle, dev, frame12):
-    """BASELINE config 3 (one frame of the batch): fp16 storage / fp32 arithmetic against the
-    fp32 oracle chain on interior windows; north-star tolerance for fp16 = 2e-3 relative, here
-    checked as an absolute bound on [0, 1] images, and +-2 LSB on the uint8 output."""
+    """BASELINE config 3 (one frame of the batch): fp16 storage / fp32 arithmetic against the fp32 oracle chain on
+    interior windows.  North-star tolerance for fp16 storage: 2e-3 RELATIVE.  The chain rounds to binary16 three times
+    (RCD, Wiener and bilateral outputs; half an ulp = 2^-12 of the value each), and the two lightness replacements move
+    every channel of a pixel together, so the error of a channel scales with the PIXEL (its largest channel), not with
+    that channel alone: a dark channel of a bright pixel legitimately carries the bright channels' rounding.  Checked as
+    |d| <= 2e-3 * max(R, G, B) per pixel; measured 1.4e-3 (profiles/r02/fp16_chain_error.json; the fp32-storage
+    chain sits at 2e-6).  The uint8 output: +-2 LSB."""
     b16 = frame12.half()
     rgb = td.RCD(dev, (W12, H12), td.BayerPattern.RGGB).process(b16)
     den = td.Wiener(dev, (W12, H12)).process_log_luminance(rgb, 0.075)
@@ -133,7 +137,9 @@ def test_full_pipeline_12mp_fp16_vs_fp32_oracle(td, oracle, dev, frame12):
     r = oracle.modify_luminance(r, oracle.bilateral(oracle.compute_luminance(r), 2.0, 0.2, 0.4))
     ref_u8 = oracle.tonemap('reinhard', r, npy(metrics), 0.75, 2.0, 1.0, 0.0)[m:-m, m:-m]
     got_rgb = npy(loc[y0:y0 + n, x0:x0 + n])
-    assert np.abs(got_rgb - r[m:-m, m:-m]).max() < 4e-3
+    ref_rgb = r[m:-m, m:-m]
+    rel = np.abs(got_rgb - ref_rgb) / np.maximum(ref_rgb.max(-1, keepdims=True), 1e-3)
+    assert rel.max() < 2e-3, rel.max()
     d = np.abs(npy(u8[y0:y0 + n, x0:x0 + n]).astype(np.int32) - ref_u8.astype(np.int32))
     assert d.max() <= 2 and (d > 1).mean() < 1e-2
 

@@ -4,8 +4,9 @@ C ABI -> kernels), against the CPU oracle on the same seeded inputs.
 Tolerance ladder (the reference itself is a fast-math CUDA build whose
 atomics are order-nondeterministic and ships no golden vectors, so parity is "unpinned" by the
 reference and anchored on the oracle's literal restatement):
-  T0 bit-exact  : codec, bilinear, PPG, RCD, colour smoothing, local green eq, white balance
-  T1 <= 2 ulp   : global green eq (ratio sum order)
+  T0 bit-exact  : codec, bilinear, PPG, RCD, colour smoothing, local green eq, white balance, bilateral
+  T1 sum order  : global green eq -- the ratio of two fp32 sums taken in different association orders; bound derived
+                  in test_postprocess_global_green_eq from the block counts (a few 1e-6 relative)
   T2 1e-5..1e-4 : anything with powf/expf/logf/cbrtf, bilateral / Wiener (sum order)
   u8 tonemaps   : +-1 LSB on a bounded fraction of samples
 """
@@ -180,10 +181,14 @@ def test_postprocess_global_green_eq(td, oracle, dev, scene):
     ws = td.PostProcess(dev, (w, h), td.BayerPattern.RGGB, color_smoothing_passes=1, green_eq_global=True, green_eq_local=True)
     got = npy(ws.process(gpu(rgb, dev)))
     ref = oracle.postprocess(rgb, oracle.RGGB, 1, True, True, 0.04)
-    # R and B never see the ratio; G1 sites are scaled by sum(G2)/sum(G1), whose fp32 summation
-    # order differs (workgroup tree here, 16x16 tree + torch.sum in the reference): a few ulp
+    # R and B never see the ratio; G1 sites are scaled by ratio = sum(G2) / sum(G1).  Both sums are fp32 sums of n = H W / 4
+    # positive terms taken in different association orders (oracle: 16 x 16 block trees, then the B block sums in sequence,
+    # postprocess.cu:193-254 + torch.sum; HIP: a tree per workgroup, then atomics): each carries a relative error of at most
+    # (depth + chain length) * 2^-24, so the two ratios differ by at most 2 * [(8 + B) + (8 + 12)] * 2^-24 relative.
+    blocks = ((h + 15) // 16) * ((w + 15) // 16)
+    bound = 2.0 * ((8 + blocks) + (8 + 12)) * 2.0 ** -24
     assert np.array_equal(got[:, :, 0::2], ref[:, :, 0::2])
-    assert np.allclose(got[:, :, 1], ref[:, :, 1], rtol=3e-6, atol=0)
+    assert np.allclose(got[:, :, 1], ref[:, :, 1], rtol=bound, atol=0), (np.abs(got[:, :, 1] / np.maximum(ref[:, :, 1], 1e-30) - 1).max(), bound)
     s32, s64 = oracle.green_eq_sums(oracle.postprocess(rgb, oracle.RGGB, 1), oracle.RGGB)
     assert abs(s64[1] / s64[0] - 1 / 1.03) < 2e-2  # the ratio the op is meant to find (scene greens differ a little)
 
@@ -448,7 +453,14 @@ def test_image_processor_end_to_end(td, oracle, dev, scene, tmp_path):
     ref = oracle.tonemap('aces', rgb, None, 2.2, 1.0, 1.0, 0.3)
     ref = np.rot90(ref, 3, (0, 1))
     d = np.abs(npy(out).astype(np.int32) - ref.astype(np.int32))
-    assert d.max() <= 2 and (d > 0).mean() < 0.02, f'max {d.max()} frac {(d > 0).mean()}'
+    assert d.max() <= 1 and (d > 0).mean() < 0.02, f'max {d.max()} frac {(d > 0).mean()}'
+    # fp16 storage between the stages (fp32 arithmetic): same picture within 1 LSB, except a handful of pixels where a
+    # rounded stage output flips a selection in a later stage (colour-smoothing medians, bilateral cell): measured 5 of
+    # 36 864 values at 2-4 LSB
+    proc16 = ImageProcessor.from_camera_settings(cam, dev, storage_dtype=torch.float16)
+    out16 = proc16.process(load_raw_bytes(raw_file, dev), 'cam')
+    d16 = np.abs(npy(out16).astype(np.int32) - ref.astype(np.int32))
+    assert out16.dtype == torch.uint8 and d16.max() <= 4 and (d16 > 1).mean() < 5e-4, f'max {d16.max()} hist {np.bincount(d16.ravel())}'
 
     with pytest.raises(Exception) as ei:
         proc.process(load_raw_bytes(raw_file, dev)[:-1], 'cam')

@@ -41,6 +41,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "tdk_color.h"
 #include "tdk_wave_fft.h"
 
@@ -152,7 +154,7 @@ template <int K, bool INV> __device__ __forceinline__ void transpose_lds(float (
 // NBUF = 2 double-buffers the hand-off block (one barrier per step); 1 when that would not leave room
 // for two workgroups per CU (K = 32, ov = 2: 32 KB per buffer).
 template <typename T, int K, int OV>
-__global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_stream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan, int vec_ok,
+__global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_stream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan0, int vec_ok,
                                                          Geom g, const float* __restrict__ sigmas, WParams prm, int nplanes, size_t plane_stride) {
   constexpr int S = K / OV, TPW = 64 / K, TR = NWV * TPW;
   constexpr int EM = 2 * S;      // columns of a tile row that become final per step (tiles a and b)
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
   constexpr int NBUF = (2 * REG * 4 * 16 <= 160 * 1024) ? 2 : 1;  // two regions (one barrier per step) if 16 waves still fit a CU
   __shared__ __align__(16) float lds[NBUF * NWV * REG];
 
+  int chan = chan0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = lane / K, row = lane & (K - 1);
   const int sidx = wave * TPW + slot;  // tile row inside the band
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
   const int jy = g.jmin + t_row;
   const T* src_row = img + (size_t)plane * plane_stride + (size_t)reflect_index(row_active ? jy * S + row : 0, H) * W * C;
   const float sigma = sigmas[chan + plane];
+  if (C == 3) chan += plane;  // interleaved input: group set p works on channel p of the same image
   const float sig2 = sigma * sigma;
   const float wy = prm.wf[row], iy = prm.wi[row];
   // the two self-conjugate lanes (kx = 0 and K/2) of every slot
@@ -200,7 +204,23 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
       {
         // ---- load the K + S samples of this lane's image row, per-tile means, analysis window
         float w[WIN];
-        if (vec_ok && C == 1 && ox >= 0 && ox + ((WIN + 3) & ~3) <= W) {
+        if (vec_ok && C == 3 && ox >= 0 && ox + ((WIN + 3) & ~3) <= W) {
+          // interleaved RGB: read whole pixels (4 pixels = 12 values per chunk, 16-B / 8-B vector loads) and keep this
+          // group's channel -- no de-interleaving pass over the image, no fp32 planes (600 MB at 50 MP)
+          auto pick = [&](auto CH) {
+#pragma unroll
+            for (int k = 0; k < ((WIN + 3) & ~3); k += 4) {
+              float t12[12];
+              rgb4_io<T>::load(src_row, (size_t)((ox + k) >> 2), t12);
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                if (k + j < WIN) w[k + j] = t12[3 * j + decltype(CH)::value];
+            }
+          };
+          if (chan == 0) pick(std::integral_constant<int, 0>{});
+          else if (chan == 1) pick(std::integral_constant<int, 1>{});
+          else pick(std::integral_constant<int, 2>{});
+        } else if (vec_ok && C == 1 && ox >= 0 && ox + ((WIN + 3) & ~3) <= W) {
           const T* p = src_row + ox;
 #pragma unroll
           for (int k = 0; k + 4 <= WIN; k += 4) {
@@ -446,26 +466,6 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
   }
 }
 
-// Multi-channel input: de-interleave HWC into fp32 planes once, so that the tile kernel reads
-// contiguous rows with 16-B loads (a strided channel read costs one cache line per sample).
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void split_planes3(const T* __restrict__ rgb, float* __restrict__ planes, int64_t npix) {
-  const int64_t ng = npix / VEC;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ng; g += (int64_t)gridDim.x * 256) {
-    float v[3 * VEC];
-    if constexpr (VEC == 4) rgb4_io<T>::load(rgb, (size_t)g, v);
-    else { v[0] = ld(rgb, (size_t)g * 3); v[1] = ld(rgb, (size_t)g * 3 + 1); v[2] = ld(rgb, (size_t)g * 3 + 2); }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      float o[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; k++) o[k] = v[3 * k + c];
-      if constexpr (VEC == 4) s4_io<float>::store(planes + (size_t)c * npix, (size_t)g, o);
-      else planes[(size_t)c * npix + g] = o[0];
-    }
-  }
-}
-
 // Finish for three planes at once: fold the slabs of each channel, normalise, write interleaved RGB.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, Geom g, WParams prm) {
@@ -580,9 +580,11 @@ template <int K> WParams make_params(const Geom& g, int ov) {
 
 template <typename T, int K, int OV>
 int launch_tiles_ov(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, const WParams& prm, hipStream_t st_, int nplanes) {
-  const int vec_ok = (C == 1) && tdk_aligned(in, 16) && (W % (16 / (int)sizeof(T)) == 0) && (g.s % (16 / (int)sizeof(T)) == 0);
+  // 16-B row loads: planar rows need W and s in whole vectors; interleaved RGB rows are read 4 pixels at a time
+  const int vec_ok = tdk_aligned(in, 16) && (C == 1 ? (W % (16 / (int)sizeof(T)) == 0) && (g.s % (16 / (int)sizeof(T)) == 0)
+                                                    : (C == 3 && W % 4 == 0 && g.s % 4 == 0));
   TDK_LAUNCH("tdk_wiener(tiles)", (wiener_stream<T, K, OV>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(64 * NWV), 0, st_, in, slabs, W, H, C, c, vec_ok, g,
-             sigmas, prm, nplanes, (size_t)W * H);
+             sigmas, prm, nplanes, C == 1 ? (size_t)W * H : (size_t)0);
   return TDK_OK;
 }
 
@@ -615,15 +617,10 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   if (C == 3) {
-    // de-interleave -> one tile launch over 3 x groups -> one finish that writes whole RGB pixels
-    const size_t cap = slab_floats(geometry(W, H, K, ov, 0));
-    float* planes = slabs + tdk_align_up(3 * cap, 64);
-    const int64_t npix = (int64_t)W * H;
+    // one tile launch over 3 x groups (group set p = channel p, read straight from the interleaved image) -> one
+    // finish that writes whole RGB pixels
     const bool vec = (W % 4) == 0 && tdk_aligned(in, 16) && tdk_aligned(out, 16);
-    const T* tin = reinterpret_cast<const T*>(in);
-    if (vec) TDK_LAUNCH("tdk_wiener(split)", (split_planes3<T, 4>), dim3(stream_blocks(npix / 4)), dim3(256), 0, st_, tin, planes, npix);
-    else TDK_LAUNCH("tdk_wiener(split)", (split_planes3<T, 1>), dim3(stream_blocks(npix)), dim3(256), 0, st_, tin, planes, npix);
-    const int rc = launch_tiles<float, K>(planes, slabs, W, H, 1, 0, ov, sigmas, g, prm, st_, 3);
+    const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, 3, 0, ov, sigmas, g, prm, st_, 3);
     if (rc != TDK_OK) return rc;
     const dim3 fgrid((unsigned)tdk_div_up(vec ? W / 4 : W, 256), (unsigned)(H < 32768 ? H : 32768));
     if (vec) TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 4>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g, prm);
@@ -665,9 +662,7 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
   const size_t slabs = slab_floats(geometry(width, height, tile_size, overlap_factor, 0));
-  if (channels == 3)  // one slab set per channel + the three de-interleaved fp32 planes
-    return tdk_align_up((tdk_align_up(3 * slabs, 64) + 3 * (size_t)width * height) * sizeof(float), 256);
-  return tdk_align_up(slabs * sizeof(float), 256);
+  return tdk_align_up((size_t)(channels == 3 ? 3 : 1) * slabs * sizeof(float), 256);  // one slab set per channel
 }
 
 TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width, int height, int channels, int tile_size, int overlap_factor,

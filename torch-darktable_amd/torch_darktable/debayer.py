@@ -54,6 +54,12 @@ class RCD:
         _expect(input_tensor, (self._rcd.height, self._rcd.width, 1), 'RCD')
         return self._rcd.process(input_tensor)
 
+    def process_packed(self, packed_data: torch.Tensor, white_balance: torch.Tensor | None = None,
+                       format_type: PackedFormat = PackedFormat.Packed12, output_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """12-bit packed bytes -> demosaiced RGB in one library call: decode12 + apply_white_balance + process,
+        with the same result as the three calls (the mosaic planes in between are never written)."""
+        return self._rcd.process_packed12(packed_data, white_balance, format_type is PackedFormat.Packed12_IDS, output_dtype)
+
     @property
     def image_size(self) -> tuple[int, int]:
         return (self._rcd.width, self._rcd.height)

@@ -35,7 +35,8 @@ class ImageSizeMismatchError(Exception):
 class ImageProcessor:
     def __init__(self, image_size: tuple[int, int], bayer_pattern: BayerPattern, packed_format: PackedFormat,
                  settings: ImageProcessingSettings, device: torch.device, white_balance: tuple[float, float, float] | None,
-                 transforms: ImageTransform | dict[str, ImageTransform] = ImageTransform.none, padding: int = 0):
+                 transforms: ImageTransform | dict[str, ImageTransform] = ImageTransform.none, padding: int = 0,
+                 storage_dtype: torch.dtype = torch.float32):
         assert device.index is not None, f'Device not fully specified: {device}'
         self.device = device
         self.settings = settings
@@ -44,6 +45,9 @@ class ImageProcessor:
         self.packed_format = packed_format
         self.transforms = transforms
         self.padding = padding
+        # image storage between the stages: float32 (the reference) or float16 (fp32 arithmetic, half the HBM traffic)
+        assert storage_dtype in (torch.float32, torch.float16)
+        self.storage_dtype = storage_dtype
         self._lum_plane: torch.Tensor | None = None  # lightness plane handed from the denoiser to the bilateral stage
         self.metrics: torch.Tensor | None = None  # moving averages, device-resident
         self.bounds: torch.Tensor | None = None
@@ -69,10 +73,10 @@ class ImageProcessor:
                 f'wb={wb}, padding={self.padding}, transform={tf}, debayer={self.settings.debayer.name}, tonemap={self.settings.tone_mapping.name})')
 
     @staticmethod
-    def from_camera_settings(camera_settings: CameraSettings, device: torch.device) -> 'ImageProcessor':
+    def from_camera_settings(camera_settings: CameraSettings, device: torch.device, storage_dtype: torch.dtype = torch.float32) -> 'ImageProcessor':
         return ImageProcessor(camera_settings.image_size, camera_settings.bayer_pattern, camera_settings.packed_format,
                               camera_settings.image_processing, device=device, white_balance=camera_settings.white_balance,
-                              transforms=camera_settings.transform, padding=camera_settings.padding)
+                              transforms=camera_settings.transform, padding=camera_settings.padding, storage_dtype=storage_dtype)
 
     def update_settings(self, settings: ImageProcessingSettings) -> None:
         """Swap settings; only workspaces whose parameters changed are rebuilt."""
@@ -119,7 +123,15 @@ class ImageProcessor:
         return decoded.view(h, w)
 
     def load_image(self, bytes: torch.Tensor) -> torch.Tensor:
-        return self.debayer(self.load_bytes(bytes))
+        if self.settings.debayer == Debayer.rcd:
+            # decode -> white balance -> RCD as one kernel (same result as load_bytes + debayer, two fp32 planes less)
+            if bytes.numel() != self.expected_bytes:
+                raise self._mismatch(f'Image size mismatch: expected {self.expected_bytes} bytes for {self.image_size} {self.packed_format.name} '
+                                     f'with {self.padding} padding, got {bytes.numel()} bytes. ')
+            payload = bytes[: bytes.numel() - self.padding] if self.padding > 0 else bytes
+            rgb = self.rcd_workspace.process_packed(payload, self.white_balance, self.packed_format, self.storage_dtype)
+            return self.postprocess_workspace.process(rgb.float()).to(self.storage_dtype) if self.settings.postprocess else rgb
+        return self.debayer(self.load_bytes(bytes)).to(self.storage_dtype)
 
     def debayer(self, bayer_image: torch.Tensor) -> torch.Tensor:
         assert bayer_image.ndim == 2, f'Bayer image must have 2 dimensions, got {bayer_image.shape}'

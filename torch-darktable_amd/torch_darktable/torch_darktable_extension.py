@@ -231,6 +231,24 @@ class RCD(_Workspace):
     return out
 
 
+  def process_packed12(self, packed: torch.Tensor, gains: torch.Tensor | None = None, ids_format: bool = False,
+                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """decode12_float -> apply_white_balance -> process as one library call (the head of the reference pipeline,
+    torch_darktable/pipeline/image_processor.py:190-255), bit for bit the result of the three calls.
+    packed: flat uint8 tensor of width * height * 3 / 2 bytes; gains: 3 floats (R, G, B) or None."""
+    _require(packed.is_cuda and packed.dtype == torch.uint8 and packed.dim() == 1, 'packed must be a 1-D uint8 CUDA tensor')
+    _require(packed.numel() == self._width * self._height * 3 // 2, 'packed size does not match the workspace image size')
+    _require(out_dtype in (torch.float32, torch.float16), 'out_dtype must be float32 or float16')
+    x = packed.contiguous()
+    g = gains.to(device=x.device, dtype=torch.float32).contiguous() if gains is not None else None
+    if g is not None:
+      _require(g.numel() == 3, 'gains must have 3 elements')
+    out = torch.empty((self._height, self._width, 3), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+      check(lib.tdk_decode12_wb_rcd(_ptr(x), _ptr(out), _ptr(g), self._width, self._height, self._pattern, int(ids_format), _dtype_tag(out), _stream()))
+    return out
+
+
 class PostProcess(_Workspace):
   """reference csrc/debayer/postprocess.cu:264-416 (extension.cpp:77-90)"""
 
