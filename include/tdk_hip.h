@@ -81,12 +81,14 @@ int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height
 
 /* decode12_float -> apply_white_balance -> RCD.process as ONE call -- the head of the reference pipeline
  * (torch_darktable/pipeline/image_processor.py:190-255: load_bytes, debayer) -- bit for bit the result of the three
- * calls: the packed bytes are decoded (csrc/packed.cu:8-31, scaled by 1/4095) and multiplied by the per-colour gain
- * with a clamp to [0, 1] (csrc/white_balance.cu:10-42) while the RCD tile is staged, so the two fp32 planes in
- * between never exist.  packed: width * height * 3 / 2 bytes; gains: 3 device floats (R, G, B) or NULL (no white
- * balance); out_dtype: storage type of rgb (H, W, 3).  width must be even. */
-int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, const float* gains, int width, int height, uint32_t pattern, int ids_format,
-                        int out_dtype, tdk_stream_t stream);
+ * calls.  Inside: one streaming kernel decodes the packed bytes (csrc/packed.cu:8-31, scaled by 1/4095) and applies the
+ * per-colour gain with a clamp to [0, 1] (csrc/white_balance.cu:10-42) into the workspace plane, then the RCD tile
+ * kernel runs on it -- one mosaic plane of traffic instead of two, two launches instead of three.
+ * packed: width * height * 3 / 2 bytes; gains: 3 device floats (R, G, B) or NULL (no white balance); workspace:
+ * tdk_decode12_wb_rcd_workspace_bytes (the fp32 mosaic); out_dtype: storage type of rgb (H, W, 3).  width must be even. */
+size_t tdk_decode12_wb_rcd_workspace_bytes(int width, int height);
+int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
+                        int ids_format, int out_dtype, tdk_stream_t stream);
 
 /* PostProcess.process: reference csrc/debayer/postprocess.cu:311-390 (extension.cpp:77-90).
  * in and out must not alias.  The global green ratio is computed and consumed on the

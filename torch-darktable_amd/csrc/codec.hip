@@ -128,6 +128,62 @@ __global__ __launch_bounds__(256) void encode12_pairs(const IN* __restrict__ in,
   out[3 * k + 2] = (uint8_t)b2;
 }
 
+// ---- decode12_float + apply_white_balance in one pass (the head of the pipeline): 8 pixels per thread, the gain of
+// each CFA site picked by its colour, clamp to [0, 1] (white_balance.cu:10-42).  Same arithmetic as the two kernels.
+__global__ __launch_bounds__(256) void decode12_wb_bulk(const uint32_t* __restrict__ in, float* __restrict__ out, int64_t ngroups, bool ids, int width,
+                                                         uint32_t pattern, const float* __restrict__ gains) {
+  const bool wb = gains != nullptr;
+  const float gr = wb ? gains[0] : 1.0f, gg = wb ? gains[1] : 1.0f, gb = wb ? gains[2] : 1.0f;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t w0 = in[3 * g], w1 = in[3 * g + 1], w2 = in[3 * g + 2];
+    uint32_t by[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      by[k] = (w0 >> (8 * k)) & 0xffu;
+      by[4 + k] = (w1 >> (8 * k)) & 0xffu;
+      by[8 + k] = (w2 >> (8 * k)) & 0xffu;
+    }
+    float px[8];
+    const int64_t i0 = 8 * g;
+    int row = (int)(i0 / width), col = (int)(i0 - (int64_t)row * width);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t p[2];
+      unpack(by[3 * k], by[3 * k + 1], by[3 * k + 2], ids, p[0], p[1]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        float v = (float)p[j] * (1.0f / 4095.0f);
+        if (wb) {
+          const int c = cfa_color(row, col, pattern);
+          v = clampf(v * (c == 0 ? gr : (c == 2 ? gb : gg)), 0.0f, 1.0f);
+        }
+        px[2 * k + j] = v;
+        if (++col == width) { col = 0; row++; }
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(out) + 2 * g;
+    o[0] = make_float4(px[0], px[1], px[2], px[3]);
+    o[1] = make_float4(px[4], px[5], px[6], px[7]);
+  }
+}
+__global__ __launch_bounds__(256) void decode12_wb_pairs(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t first, int64_t num_pairs, bool ids,
+                                                          int width, uint32_t pattern, const float* __restrict__ gains) {
+  const int64_t k = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_pairs) return;
+  uint32_t p[2];
+  unpack(in[3 * k], in[3 * k + 1], in[3 * k + 2], ids, p[0], p[1]);
+  for (int j = 0; j < 2; j++) {
+    const int64_t i = 2 * k + j;
+    const int row = (int)(i / width), col = (int)(i - (int64_t)row * width);
+    float v = (float)p[j] * (1.0f / 4095.0f);
+    if (gains) {
+      const int c = cfa_color(row, col, pattern);
+      v = clampf(v * gains[c == 0 ? 0 : (c == 2 ? 2 : 1)], 0.0f, 1.0f);
+    }
+    out[i] = v;
+  }
+}
+
 inline int bulk_grid(int64_t ngroups) {
   int64_t b = tdk_div_up64(ngroups, 256);
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -176,6 +232,24 @@ int run_encode(const IN* in, uint8_t* out, int64_t num_pairs, bool ids, float sc
 }
 
 }  // namespace
+
+// used by tdk_decode12_wb_rcd (rcd.hip)
+int tdk_decode12_wb_plane(const uint8_t* packed, float* mosaic, const float* gains, int width, int height, uint32_t pattern, int ids_format, hipStream_t s) {
+  const int64_t num_pairs = (int64_t)width * height / 2;
+  int64_t done = 0;
+  if (tdk_aligned(packed, 4) && tdk_aligned(mosaic, 16)) {
+    const int64_t ngroups = num_pairs / 4;
+    if (ngroups > 0) {
+      TDK_LAUNCH("tdk_decode12_wb", decode12_wb_bulk, dim3(bulk_grid(ngroups)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(packed), mosaic, ngroups,
+                 ids_format != 0, width, pattern, gains);
+      done = ngroups * 4;
+    }
+  }
+  if (done < num_pairs)
+    TDK_LAUNCH("tdk_decode12_wb", decode12_wb_pairs, dim3((unsigned)tdk_div_up64(num_pairs - done, 256)), dim3(256), 0, s, packed, mosaic, done, num_pairs,
+               ids_format != 0, width, pattern, gains);
+  return TDK_OK;
+}
 
 TDK_EXPORT int tdk_encode12_u16(const uint16_t* in, uint8_t* out, int64_t num_pairs, int ids_format, tdk_stream_t stream) {
   return run_encode<uint16_t>(in, out, num_pairs, ids_format != 0, 1.0f, tdk_stream(stream), "tdk_encode12_u16");

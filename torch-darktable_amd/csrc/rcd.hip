@@ -36,53 +36,22 @@ constexpr int S = RW + 2;                               // LDS row stride: even,
 constexpr int PLANE = RH * S;
 constexpr int NT = 1024;
 
-// Where the mosaic comes from: SRC(idx, row, col) with idx = row * w + col.
-//  PlainSrc    an (H, W) plane of T (RCD.process);
-//  Packed12Src the camera's 12-bit packed bytes, decoded exactly as decode12_float does (packed.cu:8-31, value *
-//              (1 / 4095)) and, with gains, white-balanced exactly as apply_white_balance does (white_balance.cu:10-42:
-//              clamp(v * gain[colour], 0, 1)) at the moment the tile is staged -- the pipeline's decode -> white balance ->
-//              demosaic (pipeline/image_processor.py:190-255) without the two fp32 planes in between.
-template <typename T> struct PlainSrc {
-  const T* p;
-  __device__ __forceinline__ float operator()(size_t idx, int, int) const { return ld(p, idx); }
-};
-struct Packed12Src {
-  const uint8_t* bytes;
-  const float* gains;  // 3 device floats (R, G, B) or nullptr
-  uint32_t pattern;
-  int ids;
-  __device__ __forceinline__ float operator()(size_t idx, int row, int col) const {
-    const uint8_t* b = bytes + (idx >> 1) * 3;
-    const uint32_t b0 = b[0], b1 = b[1], b2 = b[2];
-    uint32_t p;
-    if (ids) p = (idx & 1) ? (b1 << 4) | (b2 >> 4) : (b0 << 4) | (b2 & 0xfu);
-    else p = (idx & 1) ? (b2 << 4) | (b1 >> 4) : ((b1 & 0xfu) << 8) | b0;
-    float v = (float)p * (1.0f / 4095.0f);
-    if (gains) {
-      const int c = cfa_color(row, col, pattern);
-      v = clampf(v * gains[c == 0 ? 0 : (c == 2 ? 2 : 1)], 0.0f, 1.0f);
-    }
-    return v;
-  }
-};
-
 // v_diff / h_diff of the raw image at (fr, fc), or 0 outside step 1.1's range (rcd.cu:63-75)
-template <typename SRC>
-__device__ float diff_1_1(const SRC& in, int fr, int fc, int w, int h, bool vertical) {
+template <typename T>
+__device__ float diff_1_1(const T* __restrict__ in, int fr, int fc, int w, int h, bool vertical) {
   if (fr < 3 || fr > h - 4 || fc < 3 || fc > w - 4) return 0.0f;
+  const int st = vertical ? w : 1;
+  const size_t idx = (size_t)fr * w + fc;
   float c[7];
 #pragma unroll
-  for (int k = -3; k <= 3; k++) {
-    const int r = vertical ? fr + k : fr, cc = vertical ? fc : fc + k;
-    c[k + 3] = fmaxf(0.0f, in((size_t)r * w + cc, r, cc));
-  }
+  for (int k = -3; k <= 3; k++) c[k + 3] = fmaxf(0.0f, ld(in, idx + (ptrdiff_t)k * st));
   return sqf(c[0] - 3.0f * c[1] - c[2] + 6.0f * c[3] - c[4] - 3.0f * c[5] + c[6]);
 }
 
 // Content of the shared VP/HQ buffer at the p/q slot of odd-column site (row, col) when step
 // 4.1 did not write it.
-template <typename SRC>
-__device__ float stale_diff(const SRC& in, int row, int col, int w, int h, bool p_plane) {
+template <typename T>
+__device__ float stale_diff(const T* __restrict__ in, int row, int col, int w, int h, bool p_plane) {
   const int64_t flat = (int64_t)row * (w / 2) + (col - 1) / 2;
   return diff_1_1(in, (int)(flat / w), (int)(flat % w), w, h, p_plane);
 }
@@ -90,12 +59,12 @@ __device__ float stale_diff(const SRC& in, int row, int col, int w, int h, bool 
 // ---------------------------------------------------------------- border ring [0, 7)
 // Intermediate image of the reference's border path at (x, y): ring < 3 -> 3x3 same-colour
 // average (ppg.cu:342-389); otherwise native sample + PPG-style green (rcd.cu:285-385).
-template <typename SRC>
-__device__ f3 border_temp(const SRC& in, int x, int y, int w, int h, uint32_t pattern) {
+template <typename T>
+__device__ f3 border_temp(const T* __restrict__ in, int x, int y, int w, int h, uint32_t pattern) {
   if (x < 0 || y < 0 || x >= w || y >= h) return mk3(0.0f, 0.0f, 0.0f);
   if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3)
-    return border_average([&](int xx, int yy) { return in((size_t)yy * w + xx, yy, xx); }, x, y, w, h, pattern);
-  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? fmaxf(0.0f, in((size_t)yy * w + xx, yy, xx)) : 0.0f; };
+    return border_average([&](int xx, int yy) { return ld(in, (size_t)yy * w + xx); }, x, y, w, h, pattern);
+  auto rd = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? fmaxf(0.0f, ld(in, (size_t)yy * w + xx)) : 0.0f; };
   const int c = cfa_color(y, x, pattern);
   f3 v = mk3(0.0f, 0.0f, 0.0f);
   const float pc = rd(x, y);
@@ -112,8 +81,8 @@ __device__ f3 border_temp(const SRC& in, int x, int y, int w, int h, uint32_t pa
 }
 
 // Ring pixel number i: RBAND full rows (top + bottom) then CBAND columns of the middle rows.
-template <typename SRC, typename T>
-__device__ void border_pixel(const SRC& in, T* __restrict__ out, int w, int h, uint32_t pattern, int64_t i) {
+template <typename TI, typename T>
+__device__ void border_pixel(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int64_t i) {
   const int rband = min(h, 14), cband = min(w, 14);
   const int mid_rows = max(h - 14, 0);
   const int64_t n_rows = (int64_t)rband * w, n_cols = (int64_t)mid_rows * cband;
@@ -150,16 +119,16 @@ __device__ void border_pixel(const SRC& in, T* __restrict__ out, int w, int h, u
 }
 
 // stand-alone ring kernel: images too small to have an interior
-template <typename SRC, typename T>
-__global__ __launch_bounds__(256) void rcd_border(SRC in, T* __restrict__ out, int w, int h, uint32_t pattern) {
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern) {
   border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
 // (all the `row/col >= k && <= size - k` guards of the nine steps hold for every site the tile
 // touches): the guards compile away, which removes ~10 % of the instructions of 93 % of the tiles.
-template <typename SRC, typename T, bool INTERIOR>
-__device__ __forceinline__ void rcd_tile(const SRC& in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int tile_x, int tile_y,
+template <typename TI, typename T, bool INTERIOR>
+__device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int tile_x, int tile_y,
                                          float* __restrict__ lds) {
   float* pA = lds;               // cfa
   float* pB = lds + PLANE;       // v_diff, then p_diff at odd columns and q_diff at (odd - 1)
@@ -177,7 +146,7 @@ __device__ __forceinline__ void rcd_tile(const SRC& in, T* __restrict__ out, int
   for (int i = tid; i < RW * RH; i += NT) {
     const int r = i / RW, c = i - r * RW;
     const int gx = gx0 + c, gy = gy0 + r;
-    pA[r * S + c] = (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) ? fmaxf(0.0f, in((size_t)gy * w + gx, gy, gx)) : 0.0f;
+    pA[r * S + c] = (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
   }
   __syncthreads();
 
@@ -472,8 +441,8 @@ __device__ __forceinline__ void rcd_tile(const SRC& in, T* __restrict__ out, int
   }
 }
 
-template <typename SRC, typename T>
-__global__ __launch_bounds__(NT) void rcd_interior(SRC in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
+template <typename TI, typename T>   // TI: storage type of the mosaic, T: of the RGB result
+__global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
                                                     int tiles_x) {
   extern __shared__ float lds[];
   // The first `nborder` workgroups do the border ring (independent of the tiles: disjoint output
@@ -485,18 +454,19 @@ __global__ __launch_bounds__(NT) void rcd_interior(SRC in, T* __restrict__ out, 
   }
   const int tile = (int)blockIdx.x - nborder, tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const bool interior = tile_x >= 1 && tile_y >= 1 && tile_x * TW + TW + HALO <= w && tile_y * TH + TH + HALO <= h;
-  if (interior) rcd_tile<SRC, T, true>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
-  else rcd_tile<SRC, T, false>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
+  if (interior) rcd_tile<TI, T, true>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
+  else rcd_tile<TI, T, false>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
 }
 
-template <typename SRC, typename T>
-int launch(const SRC& in, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
+template <typename TI, typename T>
+int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
+  const TI* in = reinterpret_cast<const TI*>(bayer);
   T* out = reinterpret_cast<T*>(rgb);
   const int vec_ok = (w % 4 == 0) && tdk_aligned(rgb, 16);
   constexpr size_t lds_bytes = (size_t)5 * PLANE * sizeof(float);
-  static bool attr_set = false;  // per template instance; the attribute is a property of the function, set once per process
+  static bool attr_set = false;  // a property of the function (per template instance), set once per process
   if (!attr_set) {
-    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<SRC, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
+    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<TI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                  "tdk_rcd(hipFuncSetAttribute)");
     attr_set = true;
   }
@@ -504,13 +474,15 @@ int launch(const SRC& in, void* rgb, int w, int h, uint32_t pattern, hipStream_t
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
-    TDK_LAUNCH("tdk_rcd", (rcd_interior<SRC, T>), dim3((unsigned)(nborder + tiles_x * tiles_y)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok, nborder,
+    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)(nborder + tiles_x * tiles_y)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok, nborder,
                tiles_x);
   } else {
-    TDK_LAUNCH("tdk_rcd(border)", (rcd_border<SRC, T>), dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
+    TDK_LAUNCH("tdk_rcd(border)", (rcd_border<TI, T>), dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
   }
   return TDK_OK;
 }
+
+template <typename T> int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) { return launch_mixed<T, T>(bayer, rgb, w, h, pattern, s); }
 
 }  // namespace
 
@@ -522,18 +494,33 @@ TDK_EXPORT int tdk_rcd(const void* bayer, void* rgb, void* /*workspace*/, int wi
   TDK_REQUIRE((width & 1) == 0, "tdk_rcd: width must be even (the reference packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
               "tdk_rcd: invalid Bayer pattern 0x%08x", pattern);
-  TDK_DISPATCH_DTYPE(dtype, T, return (launch<PlainSrc<T>, T>(PlainSrc<T>{reinterpret_cast<const T*>(bayer)}, rgb, width, height, pattern, tdk_stream(stream))));
+  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, tdk_stream(stream)));
   return TDK_OK;
 }
 
-TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, const float* gains, int width, int height, uint32_t pattern, int ids_format,
-                                   int out_dtype, tdk_stream_t stream) {
-  TDK_REQUIRE(packed && rgb, "tdk_decode12_wb_rcd: null pointer");
+// decode12_float -> apply_white_balance -> RCD.process as one call.  Two launches: a streaming kernel that decodes and
+// white-balances the mosaic into the caller's fp32 scratch plane (codec.hip), then the tile kernel.  Decoding inside the
+// tile staging was built and measured SLOWER than this (profiles/rcd_packed_exp.py: 284 us + ring against 17 + 230 us):
+// the RCD kernel runs one 1024-thread workgroup per CU, so everything in its load phase is exposed latency, while a
+// streaming kernel runs at HBM speed.
+int tdk_decode12_wb_plane(const uint8_t* packed, float* mosaic, const float* gains, int width, int height, uint32_t pattern, int ids_format, hipStream_t s);
+
+TDK_EXPORT size_t tdk_decode12_wb_rcd_workspace_bytes(int width, int height) {
+  return width > 0 && height > 0 ? tdk_align_up((size_t)width * height * sizeof(float), 256) : 0;
+}
+
+TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
+                                   int ids_format, int out_dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(packed && rgb && workspace, "tdk_decode12_wb_rcd: null pointer");
   TDK_REQUIRE(width > 0 && height > 0, "tdk_decode12_wb_rcd: invalid size %dx%d", width, height);
   TDK_REQUIRE((width & 1) == 0, "tdk_decode12_wb_rcd: width must be even (pixel pairs share three bytes; RCD packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
               "tdk_decode12_wb_rcd: invalid Bayer pattern 0x%08x", pattern);
-  const Packed12Src src{packed, gains, pattern, ids_format ? 1 : 0};
-  TDK_DISPATCH_DTYPE(out_dtype, T, return (launch<Packed12Src, T>(src, rgb, width, height, pattern, tdk_stream(stream))));
-  return TDK_OK;
+  float* mosaic = reinterpret_cast<float*>(workspace);
+  const int rc = tdk_decode12_wb_plane(packed, mosaic, gains, width, height, pattern, ids_format, tdk_stream(stream));
+  if (rc != TDK_OK) return rc;
+  if (out_dtype == TDK_F32) return launch_mixed<float, float>(mosaic, rgb, width, height, pattern, tdk_stream(stream));
+  if (out_dtype == TDK_F16) return launch_mixed<float, __half>(mosaic, rgb, width, height, pattern, tdk_stream(stream));
+  tdk_set_error("unsupported dtype tag %d", out_dtype);
+  return TDK_ERR_INVALID_ARGUMENT;
 }

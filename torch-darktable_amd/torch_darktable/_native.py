@@ -31,7 +31,8 @@ SIGNATURES = {
   'tdk_ppg': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_float, c_int, c_void_p]),
   'tdk_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_void_p]),
-  'tdk_decode12_wb_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p]),
+  'tdk_decode12_wb_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
+  'tdk_decode12_wb_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p]),
   'tdk_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
   'tdk_postprocess': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_int, c_float, c_void_p]),
   'tdk_apply_white_balance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_void_p]),

@@ -245,7 +245,9 @@ class RCD(_Workspace):
       _require(g.numel() == 3, 'gains must have 3 elements')
     out = torch.empty((self._height, self._width, 3), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
-      check(lib.tdk_decode12_wb_rcd(_ptr(x), _ptr(out), _ptr(g), self._width, self._height, self._pattern, int(ids_format), _dtype_tag(out), _stream()))
+      ws = self._workspace(lib.tdk_decode12_wb_rcd_workspace_bytes(self._width, self._height), x.device)
+      check(lib.tdk_decode12_wb_rcd(_ptr(x), _ptr(out), _ptr(ws), _ptr(g), self._width, self._height, self._pattern, int(ids_format), _dtype_tag(out),
+                                    _stream()))
     return out
 
 
