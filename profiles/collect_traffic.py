@@ -29,13 +29,14 @@ from pathlib import Path
 
 # kernel function name fragment -> (TDK_LAUNCH name used by bench.py, loads are wide vector streams)
 KERNELS = {
-    'wiener_tiles': ('tdk_wiener(tiles)', True),
+    'wiener_stream': ('tdk_wiener(tiles)', True),
     'wiener_finish_modify': ('tdk_wiener(finish+modify)', False),
     'wiener_finish<': ('tdk_wiener(finish)', False),
     'rcd_interior': ('tdk_rcd', False),
     'rcd_border': ('tdk_rcd(border)', False),
     'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
-    'metrics_kernel': ('tdk_image_metrics', False),
+    'metrics_kernel': ('tdk_image_metrics_accumulate', False),
+    'metrics_finish_reset_kernel': ('tdk_image_metrics_finish', False),
     'splat_gather_kernel': ('tdk_bilateral(splat)', False),
     'blur_xy_kernel': ('tdk_bilateral(blur_xy)', False),
     'blur_z_kernel': ('tdk_bilateral(blur_z)', False),

@@ -40,6 +40,8 @@ def main():
     bil = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
     params = td.TonemapParameters(0.75, 2.0, 1.0, 0.0)
     metrics = td.compute_image_metrics([rgb], 8)
+    lum_plane = torch.empty((h, w), dtype=torch.float32, device=dev)
+    acc = td.tonemap.MetricsAccumulator(dev, stride=8)
     torch.cuda.synchronize()
     for _ in range(a.iters):
         if a.op == 'rcd':
@@ -56,11 +58,11 @@ def main():
             td.reinhard_tonemap(rgb, metrics, params)
         elif a.op == 'luminance':
             td.modify_luminance(rgb, td.compute_luminance(rgb))
-        elif a.op == 'isp':
+        elif a.op == 'isp':  # the chain bench.py times (with its stage hand-overs)
             x = rcd.process(bayer)
-            x = wiener.process_log_luminance(x, 0.075)
-            x = bil.process_rgb(x, 0.4)
-            td.reinhard_tonemap(x, td.compute_image_metrics([x], 8), params)
+            x = wiener.process_log_luminance(x, 0.075, luminance_out=lum_plane)
+            x = bil.process_rgb(x, 0.4, luminance=lum_plane, metrics=acc)
+            td.reinhard_tonemap(x, acc.finish(), params)
         else:
             raise SystemExit(f'unknown op {a.op}')
     torch.cuda.synchronize()
