@@ -29,9 +29,11 @@ from pathlib import Path
 
 # kernel function name fragment -> (TDK_LAUNCH name used by bench.py, loads are wide vector streams)
 KERNELS = {
-    'wiener_stream': ('tdk_wiener(tiles)', True),
-    'wiener_finish_modify': ('tdk_wiener(finish+modify)', False),
-    'wiener_finish<': ('tdk_wiener(finish)', False),
+    # tile kernel: every lane streams its own image row (16 B per load, 64 different rows per wave request) -> the
+    # requests are line-sized, not wide; the finish kernels read slabs and image as coalesced 16-B / 8-B streams
+    'wiener_stream': ('tdk_wiener(tiles)', False),
+    'wiener_finish_modify': ('tdk_wiener(finish+modify)', True),
+    'wiener_finish<': ('tdk_wiener(finish)', True),
     'rcd_interior': ('tdk_rcd', False),
     'rcd_border': ('tdk_rcd(border)', False),
     'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
