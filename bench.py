@@ -44,12 +44,14 @@ sys.path.insert(0, str(ROOT / 'torch-darktable_amd'))
 sys.path.insert(0, str(ROOT))
 
 # MI355X constants (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32, 2.4 GHz peak engine clock.  A wave64
-# VALU instruction occupies its SIMD for 2 cycles (4 is what ONE wave alone sustains), the
-# transcendental unit (v_exp/v_log/v_rcp/v_rsq/v_sqrt) for 8 (row 'vector-instruction ISSUE cost':
-# twice the plain cost) -- so the chip issues at most 256*4*2.4/2 = 1228.8 G plain wave-instructions/s
-# (= the 157.3 TFLOP/s fp32 vector peak with FMAs).
+# VALU instruction occupies its SIMD for 2 cycles (4 is what ONE wave alone sustains), a transcendental
+# (v_exp/v_log/v_rcp/v_rsq/v_sqrt) for 8 -- so the chip issues at most 256*4*2.4/2 = 1228.8 G plain
+# wave-instructions/s (= the 157.3 TFLOP/s fp32 vector peak with FMAs).  Measured on the box
+# (tests/hip_unit/valu_issue_bench.hip, profiles/r02/microbench.txt): 2.4 cycles plain, 8.5 transcendental,
+# and twice the plain cost for any VALU instruction with an SGPR / VCC source operand -- the floor below
+# uses the nominal 2 / 8 and is therefore optimistic.
 VALU_CUS, VALU_SIMDS, VALU_CLOCK_GHZ = 256, 4, 2.4
-VALU_CYCLES_PLAIN, VALU_CYCLES_TRANS = 2, 4
+VALU_CYCLES_PLAIN, VALU_CYCLES_TRANS = 2, 8
 VALU_PEAK_GINST = VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ / VALU_CYCLES_PLAIN
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 
@@ -260,10 +262,15 @@ def cpu_baseline(workload, threads, budget_s=25.0):
 
 
 def _git_head() -> str | None:
+    """Short hash of the sources being measured: from git, or (GPU-box snapshots carry no .git) from the
+    .git_head file a post-commit hook keeps next to the sources."""
     try:
-        return subprocess.run(['git', '-C', str(ROOT), 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        head = subprocess.run(['git', '-C', str(ROOT), 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=5).stdout.strip()
     except Exception:  # noqa: BLE001
-        return None
+        head = ''
+    if not head and (ROOT / '.git_head').exists():
+        head = (ROOT / '.git_head').read_text().strip()
+    return head or None
 
 
 def run_stub(args, ranks: Ranks):
@@ -408,13 +415,13 @@ def main(argv=None):
             insts = tj.get('_valu', {}).get(dom)    # SQ_INSTS_VALU: wave-instructions per launch (PMC pass)
             trans = tj.get('_trans', {}).get(dom)   # of which transcendental (static share of the kernel's ISA x SQ_INSTS_VALU)
             if insts:
-                # issue cycles per launch: plain instructions 2, transcendentals 4 (see the constants above)
+                # issue cycles per launch: plain instructions 2, transcendentals 8 (see the constants above)
                 cyc = insts * VALU_CYCLES_PLAIN + (trans or 0) * (VALU_CYCLES_TRANS - VALU_CYCLES_PLAIN)
                 floor_s = cyc / (VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ * 1e9)
                 valu = {'wave_insts_per_launch': insts, 'transcendental_insts_per_launch': trans,
                         'achieved_Ginst_per_s': round(insts / avg_s / 1e9, 1), 'peak_Ginst_per_s': round(VALU_PEAK_GINST, 1),
                         'alu_floor_us': round(floor_s * 1e6, 2), 'issue_frac': round(floor_s / avg_s, 4),
-                        'note': 'vector-ALU issue floor of this launch (2 cycles per wave64 instruction on a SIMD-32, 4 for transcendentals) over its '
+                        'note': 'vector-ALU issue floor of this launch (2 cycles per wave64 instruction on a SIMD-32, 8 for transcendentals) over its '
                                 'measured duration; the kernel is FP32-vector / latency bound, the HBM figures above are reported because the contract asks for them'}
         roofline = {
             'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
