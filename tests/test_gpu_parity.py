@@ -154,6 +154,48 @@ def test_rcd_negative_and_pure_function(td, oracle, dev, scene):
     assert np.array_equal(npy(a), oracle.rcd(bayer, oracle.RGGB))
 
 
+@pytest.mark.parametrize('case', ['plain', 'black_blocks', 'flat', 'wide_exponents', 'below_min', 'denormals', 'huge', 'nan'])
+def test_rcd_division_flavours_bit_exact(td, oracle, dev, scene, case):
+    """csrc/rcd.hip runs interior tiles whose samples all lie in {0} U [2^-24, 2^16] on the bare core of the IEEE
+    division (tdk_fastdiv.h) and everything else on `/`; both must give the oracle's bits.  320 x 384 has 3 x 4
+    interior tiles; the cases steer them onto either flavour and onto the per-wave fallback (zero numerators)."""
+    h, w = 320, 384
+    rng = np.random.default_rng(77)
+    bayer = oracle.mosaic(scene(h, w, 21), oracle.RGGB)[:, :, 0].copy()
+    if case == 'black_blocks':          # exact zeros inside fast tiles: numerators of steps 5.1 / 5.2 are exactly 0 there
+        bayer[70:120, 70:200] = 0.0
+        bayer[200:206, 100:300] = 0.0
+        bayer[130:190:2, 210:260:2] = 0.0
+    elif case == 'flat':                # constant patches: gradients reduce to eps, estimates cancel almost exactly
+        bayer[80:140, 80:160] = 0.5
+        bayer[150:250, 200:330] = 1.0
+    elif case == 'wide_exponents':      # every sample in range, magnitudes spread over the whole allowed interval
+        bayer = (rng.random((h, w), dtype=np.float32) + 1.0) * np.exp2(rng.integers(-24, 15, (h, w))).astype(np.float32)
+        bayer[rng.random((h, w)) < 0.1] = 0.0
+    elif case == 'below_min':           # a single sample just under 2^-24 in one tile: that tile falls back
+        bayer[100, 100] = np.float32(2.0 ** -25)
+        bayer[230, 300] = np.float32(2.0 ** -24)      # exactly the limit: still fast
+    elif case == 'denormals':
+        bayer[90:110, 90:110] = np.float32(1e-41)
+        bayer[220:230, 220:330] *= np.float32(1e-36)
+    elif case == 'huge':
+        bayer[100, 101] = np.float32(65536.0)          # the upper limit: fast
+        bayer[100, 230] = np.float32(65537.0)          # above: fallback
+        bayer[240:244, 100:104] = np.float32(3e18)     # squares overflow -> inf / nan in both implementations
+    elif case == 'nan':
+        bayer[101, 99] = np.nan                        # max(0, nan) = 0 in both
+        bayer[250, 250] = -0.0
+    bayer = np.ascontiguousarray(bayer[:, :, None], dtype=np.float32)
+    with np.errstate(all='ignore'):
+        ref = oracle.rcd(bayer, oracle.RGGB)
+    got = npy(td.RCD(dev, (w, h), td.BayerPattern.RGGB).process(gpu(bayer, dev)))
+    same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+    bad = np.argwhere(~same)
+    assert bad.size == 0, f'{case}: {len(bad)} mismatches, first at {bad[:5].tolist()}'
+    if case != 'huge':
+        assert np.isfinite(got).all()
+
+
 def test_rcd_rejects_odd_width_and_wrong_shape(td, dev):
     ws = td.RCD(dev, (64, 32), td.BayerPattern.RGGB)
     with pytest.raises(RuntimeError):

@@ -26,6 +26,7 @@
 // border ring (3x3 average + PPG-style green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is
 // computed by the first ~100 workgroups of the same launch.  Arithmetic: same operation order as
 // the oracle, no FMA contraction, IEEE divides -> bit-exact.
+#include "tdk_fastdiv.h"
 #include "tdk_stencils.h"
 
 namespace {
@@ -35,6 +36,41 @@ constexpr int RW = TW + 2 * HALO, RH = TH + 2 * HALO;  // 84 x 84 working region
 constexpr int S = RW + 2;                               // LDS row stride: even, so lanes that alternate between two rows stay on distinct banks
 constexpr int PLANE = RH * S;
 constexpr int NT = 1024;
+
+// ---------------------------------------------------------------- divisions
+// FAST tiles (interior tiles whose CFA samples all lie in {0} U [CFA_MIN, CFA_MAX], decided per tile after the
+// load phase) run the 15 divisions per pixel pair as the bare core of the IEEE expansion (tdk_fastdiv.h: same
+// bits, 25 instead of ~55 issue cycles).  Preconditions, with m = CFA_MIN = 2^-24, M = CFA_MAX = 2^16:
+//   * every denominator is eps + a sum of non-negative terms (or >= 2e-10 for the direction statistics) and is
+//     bounded by small multiples of M or M^2: 2^-33 < b < 2^44;
+//   * the numerators of steps 1.2 / 4.2 are >= 1e-10; those of step 3.1 are products of non-negative factors
+//     that are 0 or >= m^2 / 2 (cfa * 2 lpf) and, one level up, 0 or >= eps * 2^-68 = 2^-85 -- never -0, never
+//     below 2^-102;
+//   * the numerators of steps 5.1 / 5.2 are signed sums of products of differences and can cancel to anything:
+//     div_signed() checks them per wave (|a| >= 2^-80, which also excludes +-0) and falls back to `/`.
+// Tiles that fail the range check (denormal / huge / NaN samples), border tiles (their stale p/q slots alias
+// samples from outside the tile) and the border ring keep the compiler's IEEE division.
+constexpr float CFA_MIN = 0x1p-24f, CFA_MAX = 0x1p16f;
+
+template <bool FAST> __device__ __forceinline__ float div_pos(float a, float b) {
+  if constexpr (FAST) return tdk::div_core(a, b);
+  else return a / b;
+}
+
+template <bool FAST, int N> __device__ __forceinline__ void div_signed(const float (&a)[N], const float (&b)[N], float (&q)[N]) {
+  if constexpr (FAST) {
+    float mn = fabsf(a[0]);
+#pragma unroll
+    for (int i = 1; i < N; i++) mn = fminf(mn, fabsf(a[i]));
+    if (__builtin_amdgcn_ballot_w64(!(mn >= tdk::DIV_CORE_MIN_NUM)) == 0) {
+#pragma unroll
+      for (int i = 0; i < N; i++) q[i] = tdk::div_core(a[i], b[i]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = a[i] / b[i];
+}
 
 // v_diff / h_diff of the raw image at (fr, fc), or 0 outside step 1.1's range (rcd.cu:63-75)
 template <typename T>
@@ -127,9 +163,12 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
 // One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
 // (all the `row/col >= k && <= size - k` guards of the nine steps hold for every site the tile
 // touches): the guards compile away, which removes ~10 % of the instructions of 93 % of the tiles.
-template <typename TI, typename T, bool INTERIOR>
-__device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int tile_x, int tile_y,
-                                         float* __restrict__ lds) {
+template <typename TI, typename T, bool INTERIOR, bool FAST>
+__device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int tile_x, int tile_y,
+                                           float* __restrict__ lds) {
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 0) return;
+#endif
   float* pA = lds;               // cfa
   float* pB = lds + PLANE;       // v_diff, then p_diff at odd columns and q_diff at (odd - 1)
   float* pC = lds + 2 * PLANE;   // h_diff, then step-5.1 colour at R/B sites
@@ -141,14 +180,6 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
   const int gx0 = x0 - HALO, gy0 = y0 - HALO;  // global coords of local (0, 0); both even
   const int rowpar0 = cfa_color(0, 0, pattern) & 1, rowpar1 = cfa_color(1, 0, pattern) & 1;
   auto rb_par = [&](int gy) { return (gy & 1) ? rowpar1 : rowpar0; };  // column parity of the R/B sites of a row
-
-  // ---- P0: cfa = max(0, in), zero outside the image
-  for (int i = tid; i < RW * RH; i += NT) {
-    const int r = i / RW, c = i - r * RW;
-    const int gx = gx0 + c, gy = gy0 + r;
-    pA[r * S + c] = (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
-  }
-  __syncthreads();
 
   // ---- P1: step 1.1 on the halo-7 region
   {
@@ -169,6 +200,9 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
   }
   __syncthreads();
 
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 1) return;
+#endif
   // ---- P2: step 1.2 (VH_dir, halo 6) and step 2.1 (lpf at R/B sites, halo 7)
   {
     constexpr int K = 6, SW = TW + 2 * K, SH = TH + 2 * K;
@@ -182,7 +216,7 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
         const float eps = 1e-10f;
         const float V_Stat = fmaxf(eps, pB[q - S] + pB[q] + pB[q + S]);
         const float H_Stat = fmaxf(eps, pC[q - 1] + pC[q] + pC[q + 1]);
-        vh = V_Stat / (V_Stat + H_Stat);
+        vh = div_pos<FAST>(V_Stat, V_Stat + H_Stat);
       }
       pD[r * S + c] = vh;
     }
@@ -208,6 +242,9 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
   }
   __syncthreads();
 
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 2) return;
+#endif
   // ---- P3: step 3.1 (green at R/B sites, halo 5 -> pE at the green partner) and
   //          step 4.1 (p/q_diff at odd columns, halo 6 -> pB)
   {
@@ -236,12 +273,12 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
         const float W_Grad = eps + fabsf(a[-1] - a[1]) + fabsf(cfai - a[-2]) + fabsf(a[-1] - a[-3]) + fabsf(a[-2] - a[-4]);
         const float E_Grad = eps + fabsf(a[1] - a[-1]) + fabsf(cfai - a[2]) + fabsf(a[1] - a[3]) + fabsf(a[2] - a[4]);
         const float lpfi = L[0];
-        const float N_Est = a[-S] * (lpfi + lpfi) / (eps + lpfi + L[-2 * S]);
-        const float S_Est = a[S] * (lpfi + lpfi) / (eps + lpfi + L[2 * S]);
-        const float W_Est = a[-1] * (lpfi + lpfi) / (eps + lpfi + L[-2]);
-        const float E_Est = a[1] * (lpfi + lpfi) / (eps + lpfi + L[2]);
-        const float V_Est = (S_Grad * N_Est + N_Grad * S_Est) / (N_Grad + S_Grad);
-        const float H_Est = (W_Grad * E_Est + E_Grad * W_Est) / (E_Grad + W_Grad);
+        const float N_Est = div_pos<FAST>(a[-S] * (lpfi + lpfi), eps + lpfi + L[-2 * S]);
+        const float S_Est = div_pos<FAST>(a[S] * (lpfi + lpfi), eps + lpfi + L[2 * S]);
+        const float W_Est = div_pos<FAST>(a[-1] * (lpfi + lpfi), eps + lpfi + L[-2]);
+        const float E_Est = div_pos<FAST>(a[1] * (lpfi + lpfi), eps + lpfi + L[2]);
+        const float V_Est = div_pos<FAST>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
+        const float H_Est = div_pos<FAST>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
         g = mixf(V_Est, H_Est, VH_Disc);
       }
       pE[r * S + (c ^ 1)] = g;
@@ -271,6 +308,9 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
   }
   __syncthreads();
 
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 3) return;
+#endif
   // ---- P4: step 4.2 (PQ_dir at R/B sites, halo 4 -> pE, replacing lpf)
   {
     // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
@@ -289,13 +329,16 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
         const float eps = 1e-10f;
         const float P_Stat = fmaxf(eps, pB[(r - 1) * S + ocm] + pB[r * S + oc0] + pB[(r + 1) * S + ocm + 2]);
         const float Q_Stat = fmaxf(eps, pB[(r - 1) * S + ocm + 2 - 1] + pB[r * S + oc0 - 1] + pB[(r + 1) * S + ocm - 1]);
-        pq = P_Stat / (P_Stat + Q_Stat);
+        pq = div_pos<FAST>(P_Stat, P_Stat + Q_Stat);
       }
       pE[r * S + c] = pq;
     }
   }
   __syncthreads();
 
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 4) return;
+#endif
   // ---- P5: step 5.1 (opposite colour at R/B sites, halo 3 -> pC)
   {
     // checkerboard lane mapping: consecutive lanes take consecutive columns of a 2-row band, each
@@ -332,15 +375,20 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
         const float NE_Est = a[-S + 1] - G(-1, 1);
         const float SW_Est = a[S - 1] - G(1, -1);
         const float SE_Est = a[S + 1] - G(1, 1);
-        const float P_Est = (NW_Grad * SE_Est + SE_Grad * NW_Est) / (NW_Grad + SE_Grad);
-        const float Q_Est = (NE_Grad * SW_Est + SW_Grad * NE_Est) / (NE_Grad + SW_Grad);
-        val = g0 + mixf(P_Est, Q_Est, PQ_Disc);
+        const float num[2] = {NW_Grad * SE_Est + SE_Grad * NW_Est, NE_Grad * SW_Est + SW_Grad * NE_Est};
+        const float den[2] = {NW_Grad + SE_Grad, NE_Grad + SW_Grad};
+        float est[2];  // P_Est, Q_Est
+        div_signed<FAST>(num, den, est);
+        val = g0 + mixf(est[0], est[1], PQ_Disc);
       }
       pC[r * S + c] = val;
     }
   }
   __syncthreads();
 
+#ifdef TDK_RCD_STOP
+  if (TDK_RCD_STOP == 5) return;
+#endif
   // ---- P6: step 5.2 at green sites + write_output (margin 7), half a tile (32 rows) at a time.
   // One lane per COLUMN of a 2-row band (checkerboard, as above) produces the band's green site and
   // R/B site of that column; the two pixels are then sorted by ROW, so that for each row the wave
@@ -383,7 +431,7 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
           const float gW = pE[r * S + ((c - 1) ^ 1)], gE = pE[r * S + ((c + 1) ^ 1)];
           // colour `row_color` is native left/right (this row's R/B sites) and from step 5.1
           // above/below; the other colour the other way round.
-          float res[2];
+          float num[4], den[4], est[4];  // V_Est, H_Est of rgb0 then of rgb2
 #pragma unroll
           for (int ci = 0; ci < 2; ci++) {
             const int col = ci * 2;  // rgbc = rgb0 then rgb2 (rcd.cu:256-258)
@@ -402,13 +450,15 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
             const float S_Est = cS - gS;
             const float W_Est = cW - gW;
             const float E_Est = cE - gE;
-            const float V_Est = (N_Grad * S_Est + S_Grad * N_Est) / (N_Grad + S_Grad);
-            const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
-            res[ci] = g + mixf(V_Est, H_Est, VH_Disc);
+            num[2 * ci] = N_Grad * S_Est + S_Grad * N_Est;
+            den[2 * ci] = N_Grad + S_Grad;
+            num[2 * ci + 1] = E_Grad * W_Est + W_Grad * E_Est;
+            den[2 * ci + 1] = E_Grad + W_Grad;
           }
-          gpx[0] = fmaxf(res[0], 0.0f);
+          div_signed<FAST>(num, den, est);
+          gpx[0] = fmaxf(g + mixf(est[0], est[1], VH_Disc), 0.0f);
           gpx[1] = fmaxf(g, 0.0f);
-          gpx[2] = fmaxf(res[1], 0.0f);
+          gpx[2] = fmaxf(g + mixf(est[2], est[3], VH_Disc), 0.0f);
         }
         // --- sort by row and write: row ty_a holds this column's R/B pixel when rb_off == 0, else its green pixel
 #pragma unroll
@@ -441,29 +491,143 @@ __device__ __forceinline__ void rcd_tile(const TI* __restrict__ in, T* __restric
   }
 }
 
-template <typename TI, typename T>   // TI: storage type of the mosaic, T: of the RGB result
-__global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int vec_ok, int nborder,
-                                                    int tiles_x) {
-  extern __shared__ float lds[];
-  // The first `nborder` workgroups do the border ring (independent of the tiles: disjoint output
-  // pixels, input read-only), so the ring costs a few workgroup slots inside this launch instead
-  // of a latency-bound launch of its own.
-  if ((int)blockIdx.x < nborder) {
-    border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * NT + threadIdx.x);
-    return;
+// ---------------------------------------------------------------- load phase
+// The 84 x 84 sample window of an interior tile as 8-B (fp32) / 4-B (fp16) pairs: 84 rows x 42 pairs = 3528
+// loads per tile, at most PAIRS_PT = 4 per thread.  The persistent workgroup issues them for its NEXT tile
+// right after the load barrier of the current one, so they are in flight during the six compute phases: with one
+// 1024-thread workgroup per CU nothing else can hide that latency (measured: the load phase alone was 46 us of
+// the 225 us kernel).  Needs w even (always) and an 8-B / 4-B aligned base pointer (`wide_ok`).
+constexpr int PAIRS_ROW = RW / 2, PAIRS = PAIRS_ROW * RH, PAIRS_PT = (PAIRS + NT - 1) / NT;
+
+template <typename TI> struct Staged;
+template <> struct Staged<float> {
+  float2 v[PAIRS_PT];
+  __device__ __forceinline__ void fetch(const float* p, int k) { v[k] = *reinterpret_cast<const float2*>(p); }
+  __device__ __forceinline__ float2 get(int k) const { return v[k]; }
+};
+template <> struct Staged<__half> {
+  uint32_t v[PAIRS_PT];
+  __device__ __forceinline__ void fetch(const __half* p, int k) { v[k] = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ float2 get(int k) const { return __half22float2(__builtin_bit_cast(__half2, v[k])); }
+};
+
+template <typename TI>
+__device__ __forceinline__ void prefetch_tile(Staged<TI>& st, const TI* __restrict__ in, int w, int tile_x, int tile_y) {
+  const int gx0 = tile_x * TW - HALO, gy0 = tile_y * TH - HALO;
+#pragma unroll
+  for (int k = 0; k < PAIRS_PT; k++) {
+    const int j = (int)threadIdx.x + k * NT;
+    if (j < PAIRS) {
+      const int r = j / PAIRS_ROW, cp = j - r * PAIRS_ROW;
+      st.fetch(in + (size_t)(gy0 + r) * w + gx0 + 2 * cp, k);
+    }
   }
-  const int tile = (int)blockIdx.x - nborder, tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-  const bool interior = tile_x >= 1 && tile_y >= 1 && tile_x * TW + TW + HALO <= w && tile_y * TH + TH + HALO <= h;
-  if (interior) rcd_tile<TI, T, true>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
-  else rcd_tile<TI, T, false>(in, out, w, h, pattern, vec_ok, tile_x, tile_y, lds);
+}
+
+struct Range {  // of the staged samples, as bit patterns: samples are >= +0, so integer order == float order
+  uint32_t lo = 0xffffffffu, hi = 0u;  // min over (bits - 1) [zero wraps to the top: zeros are allowed], max over bits
+  __device__ __forceinline__ void add(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    lo = min(lo, u - 1u);
+    hi = max(hi, u);
+  }
+  __device__ __forceinline__ bool ok() const { return lo >= __builtin_bit_cast(uint32_t, CFA_MIN) - 1u && hi <= __builtin_bit_cast(uint32_t, CFA_MAX); }
+};
+
+// P0: cfa = max(0, in) into plane A (zero outside the image; a NaN cannot survive v_max_f32 with 0), from the
+// staged pairs when the tile was prefetched, else by scalar loads.  Interior tiles also decide the division
+// flavour: every thread tracks the range of what it stages, each wave posts its verdict, and after the load
+// barrier every thread folds the 16 verdicts -- a workgroup-uniform answer.  Returns after that barrier.
+template <typename TI, bool INTERIOR>
+__device__ __forceinline__ bool load_tile(const TI* __restrict__ in, int w, int h, int tile_x, int tile_y, float* __restrict__ lds, const Staged<TI>* st) {
+  float* pA = lds;
+  const int tid = threadIdx.x;
+  const int gx0 = tile_x * TW - HALO, gy0 = tile_y * TH - HALO;
+  Range rg;
+  if (INTERIOR && st) {
+#pragma unroll
+    for (int k = 0; k < PAIRS_PT; k++) {
+      const int j = tid + k * NT;
+      if (j < PAIRS) {
+        const int r = j / PAIRS_ROW, cp = j - r * PAIRS_ROW;
+        const float2 s2 = st->get(k);
+        const float a = fmaxf(0.0f, s2.x), b = fmaxf(0.0f, s2.y);
+        *reinterpret_cast<float2*>(pA + r * S + 2 * cp) = make_float2(a, b);  // S even: 8-B aligned
+        rg.add(a);
+        rg.add(b);
+      }
+    }
+  } else {
+    for (int i = tid; i < RW * RH; i += NT) {
+      const int r = i / RW, c = i - r * RW;
+      const int gx = gx0 + c, gy = gy0 + r;
+      const float v = (INTERIOR || (gx >= 0 && gy >= 0 && gx < w && gy < h)) ? fmaxf(0.0f, ld(in, (size_t)gy * w + gx)) : 0.0f;
+      pA[r * S + c] = v;
+      if constexpr (INTERIOR) rg.add(v);
+    }
+  }
+  if constexpr (INTERIOR) {
+    uint32_t* verdict = reinterpret_cast<uint32_t*>(lds + 5 * PLANE);  // NT / 64 = 16 words behind the planes
+    const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
+    if ((tid & 63) == 0) verdict[tid >> 6] = wave_ok ? 1u : 0u;
+    __syncthreads();
+    uint32_t all = 1u;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) all &= verdict[k];
+    return __builtin_amdgcn_readfirstlane(all) != 0;
+  } else {
+    __syncthreads();
+    return false;
+  }
+}
+
+// Persistent workgroups (one per CU: the five planes fill its LDS).  Work list: `nborder` chunks of the border
+// ring (independent of the tiles: disjoint output pixels, input read-only), then the tiles; workgroup b takes
+// tiles b, b + G, b + 2G, ...  The column of a tile is rotated by 7 per tile row so that the slower border-column
+// tiles spread over the workgroups instead of landing on the same two.
+template <typename TI, typename T>   // TI: storage type of the mosaic, T: of the RGB result
+__global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int wide_ok, int nborder,
+                                                    int tiles_x, int tiles_y) {
+  extern __shared__ float lds[];
+  const int G = (int)gridDim.x, ntiles = tiles_x * tiles_y;
+  for (int i = (int)blockIdx.x; i < nborder; i += G) border_pixel(in, out, w, h, pattern, (int64_t)i * NT + threadIdx.x);
+
+  auto locate = [&](int t, int& tx, int& ty) -> bool {  // tile number -> position; true: clear of every image-border rule
+    ty = t / tiles_x;
+    tx = (t - ty * tiles_x + 7 * ty) % tiles_x;
+    return tx >= 1 && ty >= 1 && tx * TW + TW + HALO <= w && ty * TH + TH + HALO <= h;
+  };
+  Staged<TI> st;
+  int t = (int)blockIdx.x, tx = 0, ty = 0;
+  bool interior = false, staged = false;
+  if (t < ntiles) {
+    interior = locate(t, tx, ty);
+    if (interior && wide_ok) { prefetch_tile(st, in, w, tx, ty); staged = true; }
+  }
+  while (t < ntiles) {
+    const bool fast = interior ? load_tile<TI, true>(in, w, h, tx, ty, lds, staged ? &st : nullptr) : load_tile<TI, false>(in, w, h, tx, ty, lds, nullptr);
+    // next tile: position, and its samples on their way while this one computes
+    const int tn = t + G;
+    int txn = 0, tyn = 0;
+    bool interior_n = false, staged_n = false;
+    if (tn < ntiles) {
+      interior_n = locate(tn, txn, tyn);
+      if (interior_n && wide_ok) { prefetch_tile(st, in, w, txn, tyn); staged_n = true; }
+    }
+    if (!interior) rcd_phases<TI, T, false, false>(in, out, w, h, pattern, tx, ty, lds);
+    else if (fast) rcd_phases<TI, T, true, true>(in, out, w, h, pattern, tx, ty, lds);
+    else rcd_phases<TI, T, true, false>(in, out, w, h, pattern, tx, ty, lds);
+    __syncthreads();  // the last phase reads planes the next load phase overwrites
+    t = tn; tx = txn; ty = tyn; interior = interior_n; staged = staged_n;
+  }
 }
 
 template <typename TI, typename T>
 int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
   const TI* in = reinterpret_cast<const TI*>(bayer);
   T* out = reinterpret_cast<T*>(rgb);
-  const int vec_ok = (w % 4 == 0) && tdk_aligned(rgb, 16);
-  constexpr size_t lds_bytes = (size_t)5 * PLANE * sizeof(float);
+  const int wide_ok = tdk_aligned(bayer, 2 * sizeof(TI));  // sample pairs load as one 8-B / 4-B access (w is even)
+  constexpr size_t lds_bytes = (size_t)5 * PLANE * sizeof(float) + (NT / 64) * sizeof(uint32_t);  // planes + the per-wave range verdicts
   static bool attr_set = false;  // a property of the function (per template instance), set once per process
   if (!attr_set) {
     TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<TI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
@@ -474,8 +638,10 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
-    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)(nborder + tiles_x * tiles_y)), dim3(NT), lds_bytes, s, in, out, w, h, pattern, vec_ok, nborder,
-               tiles_x);
+    int grid = tdk_device_cus();  // one resident workgroup per CU
+    if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + tiles_x * tiles_y;  // experiments: 0 = one item per workgroup
+    if (grid > nborder + tiles_x * tiles_y) grid = nborder + tiles_x * tiles_y;
+    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y);
   } else {
     TDK_LAUNCH("tdk_rcd(border)", (rcd_border<TI, T>), dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
   }

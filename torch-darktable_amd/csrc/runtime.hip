@@ -11,6 +11,16 @@
 
 static thread_local char g_last_error[512] = "";
 
+int tdk_device_cus() {
+  static int cus = 0;  // one device type per process; a stale value only changes launch shapes, never results
+  if (cus == 0) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+
 void tdk_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

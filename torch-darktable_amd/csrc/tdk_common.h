@@ -17,6 +17,7 @@
 
 // ---------------------------------------------------------------- host side: status + launch checks
 void tdk_set_error(const char* fmt, ...);
+int tdk_device_cus();  // compute units of the current device (cached)
 
 #define TDK_REQUIRE(cond, ...)                 \
   do {                                         \

@@ -528,16 +528,6 @@ Geom geometry(int W, int H, int K, int ov, int G) {
 
 size_t slab_floats(const Geom& g) { return (size_t)g.ngx * g.ngy * g.RSXP * g.RSY; }
 
-int device_cus() {
-  static int cus = 0;  // one device type per process; a stale value only changes the group width, never the result
-  if (cus == 0) {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
-  }
-  return cus;
-}
-
 // Group width: the launch is one workgroup per group with `per_cu` workgroups resident per CU, so the run
 // time is ceil(groups / slots) rounds of one group's duration -- pick the width whose last round is
 // fullest (ties: wider groups = fewer seam columns), never using more slab than the workspace (G_MIN) holds.
@@ -546,7 +536,7 @@ int pick_group_width(int W, int H, int K, int ov, int nplanes, int per_cu) {
     const int G = atoi(e);
     if (G >= G_MIN && G <= G_MAX && (G & 1) == 0) return G;
   }
-  const int slots = device_cus() * per_cu;
+  const int slots = tdk_device_cus() * per_cu;
   const size_t cap = slab_floats(geometry(W, H, K, ov, 0));
   int best = G_MIN;
   double best_eff = -1.0;
