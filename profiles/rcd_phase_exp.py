@@ -2,7 +2,9 @@
 after phase k (results are wrong, only the duration matters):
     for k in 0..5: TDK_EXTRA_FLAGS=-DTDK_RCD_STOP=$k python torch-darktable_amd/build.py --force; cp .../libtdk_hip.so variants/rcd_stop$k.so
     python profiles/rcd_phase_exp.py variants/rcd_stop*.so variants/rcd_full.so
-Each library is timed in its own process (12 MP, fp16 in / fp16 out and fp32 / fp32)."""
+Each library is timed in its own process (12 MP, fp16 in / fp16 out and fp32 / fp32).
+A library built with -DTDK_RCD_TIMING=1 also reports clock64() deltas per phase of one workgroup (entries: 0 = end
+barrier + load phase + prefetch issue, 1..6 = phases P1..P6), in cycles per tile."""
 import ctypes as C
 import json
 import subprocess
@@ -32,6 +34,13 @@ def child(path):
         b.record()
         torch.cuda.synchronize()
         out[name] = round(a.elapsed_time(b) / 30 * 1e3, 1)
+        if hasattr(lib, 'tdk_debug_rcd_phase_cycles'):
+            buf = (C.c_ulonglong * 16)()
+            lib.tdk_debug_rcd_phase_cycles(buf, 1)   # reset
+            run()
+            torch.cuda.synchronize()
+            lib.tdk_debug_rcd_phase_cycles(buf, 1)
+            out[name + '_cycles_per_tile'] = [round(buf[k] / 12) for k in range(12)]   # workgroup 3 of 256 owns 12 tiles at 12 MP
     print(json.dumps(out))
 
 

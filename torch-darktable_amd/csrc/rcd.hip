@@ -29,6 +29,19 @@
 #include "tdk_fastdiv.h"
 #include "tdk_stencils.h"
 
+#ifdef TDK_RCD_TIMING
+// experiments: per-phase clock64() deltas of one workgroup, summed over its tiles (profiles/rcd_phase_exp.py)
+__device__ unsigned long long g_rcd_phase_cycles[16], g_rcd_t0;
+#define RCD_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) { const unsigned long long t_ = clock64(); atomicAdd(&g_rcd_phase_cycles[k], t_ - g_rcd_t0); g_rcd_t0 = t_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int tdk_debug_rcd_phase_cycles(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rcd_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rcd_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define RCD_MARK(k)
+#endif
+
 namespace {
 
 constexpr int TW = 64, TH = 64, HALO = 10;
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
 template <typename TI, typename T, bool INTERIOR, bool FAST>
 __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int tile_x, int tile_y,
                                            float* __restrict__ lds) {
+  RCD_MARK(0);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 0) return;
 #endif
@@ -200,6 +214,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
   }
   __syncthreads();
 
+  RCD_MARK(1);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 1) return;
 #endif
@@ -242,6 +257,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
   }
   __syncthreads();
 
+  RCD_MARK(2);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 2) return;
 #endif
@@ -308,6 +324,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
   }
   __syncthreads();
 
+  RCD_MARK(3);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 3) return;
 #endif
@@ -336,6 +353,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
   }
   __syncthreads();
 
+  RCD_MARK(4);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 4) return;
 #endif
@@ -386,6 +404,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
   }
   __syncthreads();
 
+  RCD_MARK(5);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 5) return;
 #endif
@@ -489,6 +508,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
       }
     }
   }
+  RCD_MARK(6);
 }
 
 // ---------------------------------------------------------------- load phase
@@ -597,6 +617,9 @@ __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T*
     tx = (t - ty * tiles_x + 7 * ty) % tiles_x;
     return tx >= 1 && ty >= 1 && tx * TW + TW + HALO <= w && ty * TH + TH + HALO <= h;
   };
+#ifdef TDK_RCD_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) g_rcd_t0 = clock64();
+#endif
   Staged<TI> st;
   int t = (int)blockIdx.x, tx = 0, ty = 0;
   bool interior = false, staged = false;
