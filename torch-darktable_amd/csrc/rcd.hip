@@ -31,8 +31,10 @@
 
 #ifdef TDK_RCD_TIMING
 // experiments: per-phase clock64() deltas of one workgroup, summed over its tiles (profiles/rcd_phase_exp.py)
-__device__ unsigned long long g_rcd_phase_cycles[16], g_rcd_t0;
-#define RCD_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) { const unsigned long long t_ = clock64(); atomicAdd(&g_rcd_phase_cycles[k], t_ - g_rcd_t0); g_rcd_t0 = t_; } } while (0)
+__device__ unsigned long long g_rcd_phase_cycles[16];
+#define RCD_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) { const unsigned long long t_ = clock64(); atomicAdd(&g_rcd_phase_cycles[k], t_ - rcd_t0); rcd_t0 = t_; } } while (0)
+#define RCD_T0_PARAM , unsigned long long& rcd_t0
+#define RCD_T0_ARG , rcd_t0
 extern "C" __attribute__((visibility("default"))) int tdk_debug_rcd_phase_cycles(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rcd_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rcd_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
@@ -40,6 +42,8 @@ extern "C" __attribute__((visibility("default"))) int tdk_debug_rcd_phase_cycles
 }
 #else
 #define RCD_MARK(k)
+#define RCD_T0_PARAM
+#define RCD_T0_ARG
 #endif
 
 namespace {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
 // touches): the guards compile away, which removes ~10 % of the instructions of 93 % of the tiles.
 template <typename TI, typename T, bool INTERIOR, bool FAST>
 __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int tile_x, int tile_y,
-                                           float* __restrict__ lds) {
+                                           float* __restrict__ lds RCD_T0_PARAM) {
   RCD_MARK(0);
 #ifdef TDK_RCD_STOP
   if (TDK_RCD_STOP == 0) return;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T*
     return tx >= 1 && ty >= 1 && tx * TW + TW + HALO <= w && ty * TH + TH + HALO <= h;
   };
 #ifdef TDK_RCD_TIMING
-  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) g_rcd_t0 = clock64();
+  unsigned long long rcd_t0 = clock64();
 #endif
   Staged<TI> st;
   int t = (int)blockIdx.x, tx = 0, ty = 0;
@@ -637,9 +641,9 @@ __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T*
       interior_n = locate(tn, txn, tyn);
       if (interior_n && wide_ok) { prefetch_tile(st, in, w, txn, tyn); staged_n = true; }
     }
-    if (!interior) rcd_phases<TI, T, false, false>(in, out, w, h, pattern, tx, ty, lds);
-    else if (fast) rcd_phases<TI, T, true, true>(in, out, w, h, pattern, tx, ty, lds);
-    else rcd_phases<TI, T, true, false>(in, out, w, h, pattern, tx, ty, lds);
+    if (!interior) rcd_phases<TI, T, false, false>(in, out, w, h, pattern, tx, ty, lds RCD_T0_ARG);
+    else if (fast) rcd_phases<TI, T, true, true>(in, out, w, h, pattern, tx, ty, lds RCD_T0_ARG);
+    else rcd_phases<TI, T, true, false>(in, out, w, h, pattern, tx, ty, lds RCD_T0_ARG);
     __syncthreads();  // the last phase reads planes the next load phase overwrites
     t = tn; tx = txn; ty = tyn; interior = interior_n; staged = staged_n;
   }
