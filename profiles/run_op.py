@@ -1,7 +1,7 @@
 """Run one op of the hot path a few times on synthetic 12 MP data -- the target of the
 rocprofv3 passes whose summaries are committed in this directory.
 
-  python profiles/run_op.py {rcd,ppg,postprocess,wiener,bilateral,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
+  python profiles/run_op.py {rcd,ppg,postprocess,wiener,bilateral,laplacian,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
 """
 import argparse
 import sys
@@ -38,6 +38,8 @@ def main():
     loglum = td.compute_log_luminance(rgb, 1e-4)
     wiener = td.Wiener(dev, (w, h), 4, 32)
     bil = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
+    lap = td.Laplacian(dev, (w, h), td.LaplacianParams(6, 0.2, 1.6, 0.7, 0.3)) if a.op == 'laplacian' else None
+    lum32 = lum.float()
     params = td.TonemapParameters(0.75, 2.0, 1.0, 0.0)
     metrics = td.compute_image_metrics([rgb], 8)
     lum_plane = torch.empty((h, w), dtype=torch.float32, device=dev)
@@ -54,6 +56,8 @@ def main():
             wiener.process(loglum.unsqueeze(2), 0.075)
         elif a.op == 'bilateral':
             bil.process(lum, 0.4)
+        elif a.op == 'laplacian':
+            lap.process(lum32)
         elif a.op == 'tonemap':
             td.reinhard_tonemap(rgb, metrics, params)
         elif a.op == 'luminance':

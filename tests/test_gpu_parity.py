@@ -421,6 +421,18 @@ def test_wiener_log_luminance_pipeline(td, oracle, dev, scene, size):
     assert np.abs(got - npy(chain)).max() < 2e-6
 
 
+@pytest.mark.parametrize('size', [(120, 161), (4, 4), (7, 9), (16, 16), (33, 70), (256, 200), (301, 515), (600, 1100)])
+def test_laplacian_level_schedules(td, oracle, dev, scene, size):
+    """Image sizes that take every branch of the launch schedule in csrc/laplacian.hip: two levels only, everything
+    inside the single-workgroup kernels, a single reduce launch, a reduce pair, tiled assembles."""
+    h, w = size
+    lum = oracle.compute_luminance(scene(max(h, 8), max(w, 8), 31))[:h, :w].copy()
+    prm = (0.25, 1.4, 0.8, 0.2)
+    got = npy(td.Laplacian(dev, (w, h), td.LaplacianParams(6, *prm)).process(gpu(lum, dev)))
+    d = np.abs(got - oracle.laplacian(lum, *prm))
+    assert np.isfinite(got).all() and d.max() < 4e-3 and (d > 1e-5).mean() < 2e-2, (size, d.max(), (d > 1e-5).mean())
+
+
 @pytest.mark.parametrize('prm', [(0.2, 1.0, 1.0, 0.0), (0.2, 1.6, 0.7, 0.3), (0.35, 0.5, 1.5, -0.2)])
 def test_laplacian(td, oracle, dev, scene, prm):
     h, w = 120, 161
@@ -428,9 +440,11 @@ def test_laplacian(td, oracle, dev, scene, prm):
     ws = td.Laplacian(dev, (w, h), td.LaplacianParams(6, *prm))
     got = npy(ws.process(gpu(lum, dev)))
     ref = oracle.laplacian(lum, *prm)
-    # fp16 storage at every level: an fp32-math difference of 1 ulp can flip a half rounding
+    # fp16 storage at every level: an fp32-math difference of 1 ulp can flip a half rounding (one binary16 ulp of the result,
+    # 4.9e-4 below 1.0); the curve is evaluated in a factored form with FMA contraction (csrc/laplacian.hip), so about 1 %
+    # of the pixels see such a flip somewhere in their pyramid
     d = np.abs(got - ref)
-    assert d.max() < 4e-3 and (d > 1e-5).mean() < 5e-3
+    assert d.max() < 4e-3 and (d > 1e-5).mean() < 2e-2
     with pytest.raises(RuntimeError):
         td.Laplacian(dev, (w, h), td.LaplacianParams(num_gamma=4))
 
