@@ -17,5 +17,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/valu -o v -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_valu.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -o s -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq2.log 2>&1 || echo "sq2 pass failed (optional)"
-python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json $OUT/valu $GIT $OUT/sq2 > $OUT/traffic.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/sq3 -o t -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq3.log 2>&1 || echo "sq3 pass failed (optional)"
+python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json $OUT/valu $GIT $OUT/sq2 $OUT/sq3 > $OUT/traffic.log 2>&1 || exit 1
 echo capture done

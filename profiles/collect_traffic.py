@@ -14,7 +14,7 @@ tallied at HALF its bytes, so the read side is doubled for kernels whose loads a
 below, 8-B) vector streams (marked WIDE); other access widths are reported uncorrected (uncalibrated).
 WRITE_SIZE needs no correction.  Values are means over the launches seen.
 
-Transcendental share: SQ has no per-class VALU counter on gfx950, so the count is the kernel's STATIC share
+Transcendentals: SQ_INSTS_VALU_TRANS_F32 when one of the passes collected it; otherwise the kernel's STATIC share
 of v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos among its VALU instructions (from the code object's
 disassembly, profiles/isa_mix.py) times the measured SQ_INSTS_VALU -- exact for straight-line streaming
 kernels, an estimate for kernels with data-dependent branches.
@@ -106,7 +106,11 @@ def main():
         detail[name] = {'FETCH_SIZE_raw': fetch.get(frag), 'WRITE_SIZE_raw': write.get(frag), 'read_bytes': int(rd), 'write_bytes': int(wr),
                         'read_doubled': wide}
     valu_named = {KERNELS[k][0]: int(v) for k, v in valu.items()}
-    trans_named = {KERNELS[k][0]: int(v * share[k]) for k, v in valu.items() if k in share}
+    measured_trans = sq.get('SQ_INSTS_VALU_TRANS_F32', {})
+    if measured_trans:   # the counter exists on gfx950: prefer it over the static share
+        trans_named = {KERNELS[k][0]: int(v) for k, v in measured_trans.items()}
+    else:
+        trans_named = {KERNELS[k][0]: int(v * share[k]) for k, v in valu.items() if k in share}
     sq_named = {c: {KERNELS[k][0]: round(v, 1) for k, v in per.items()} for c, per in sq.items()}
     json.dump({**result, '_valu': valu_named, '_trans': trans_named, '_sq': sq_named, '_detail': detail, '_git': git,
                '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'}, open(out, 'w'), indent=1)

@@ -538,8 +538,7 @@ int launch_tiles(const TL* lum, const T* rgb, T* out, int width, int height, con
   const dim3 grid(8 * tdk_div_up(ntiles, 8));
 #define TDK_BT(VECV, MAXCV)                                                                                                                       \
   do {                                                                                                                                            \
-    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>),                             \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "tdk_bilateral(hipFuncSetAttribute)");          \
+    TDK_MAX_LDS_ONCE((bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), "tdk_bilateral(hipFuncSetAttribute)");                                    \
     TDK_LAUNCH("tdk_bilateral(tiles)", (bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), grid, dim3(FNT), lds_bytes, s, lum, rgb, out, width, height, d, \
                sigma_s, sigma_r, detail, tiles_x, ntiles, L);                                                                                     \
   } while (0)
@@ -555,12 +554,10 @@ int build_grid(const T* in, float* grid, float* tmp, int width, int height, cons
   const size_t splat_lds = (size_t)d.sz * 256 * sizeof(float);
   const dim3 sgrid(tdk_div_up(d.sx, 32), tdk_div_up(d.sy, 8));
   if (2.0f * sigma_s + 5.0f <= 10.0f) {
-    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
-                 "tdk_bilateral(hipFuncSetAttribute)");
+    TDK_MAX_LDS_ONCE((splat_gather_kernel<T, 10>), "tdk_bilateral(hipFuncSetAttribute)");
     TDK_LAUNCH("tdk_bilateral(splat)", (splat_gather_kernel<T, 10>), sgrid, dim3(256), splat_lds, s, in, grid, width, height, d, sigma_s, sigma_r);
   } else {
-    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&splat_gather_kernel<T, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds),
-                 "tdk_bilateral(hipFuncSetAttribute)");
+    TDK_MAX_LDS_ONCE((splat_gather_kernel<T, 24>), "tdk_bilateral(hipFuncSetAttribute)");
     TDK_LAUNCH("tdk_bilateral(splat)", (splat_gather_kernel<T, 24>), sgrid, dim3(256), splat_lds, s, in, grid, width, height, d, sigma_s, sigma_r);
   }
   TDK_LAUNCH("tdk_bilateral(blur_xy)", blur_xy_kernel, dim3(tdk_div_up(d.sx, BTW), tdk_div_up(d.sy, BTH), d.sz), dim3(256), 0, s, grid, tmp, d);

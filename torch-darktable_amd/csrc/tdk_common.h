@@ -60,6 +60,17 @@ extern bool g_tdk_profile_on;
     TDK_CHECK_LAUNCH(name);                                                           \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit to the CU's 160 KB once per process and template instance (a property of the
+// function, not of the launch): keeps hipFuncSetAttribute off the per-call path.
+#define TDK_MAX_LDS_ONCE(kernel, what)                                                                                                     \
+  do {                                                                                                                                      \
+    static bool tdk_attr_set_ = false;                                                                                                      \
+    if (!tdk_attr_set_) {                                                                                                                   \
+      TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), what); \
+      tdk_attr_set_ = true;                                                                                                                 \
+    }                                                                                                                                       \
+  } while (0)
+
 static inline int tdk_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t tdk_div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t tdk_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
