@@ -12,6 +12,8 @@ One step = one pass of the hot path over one batch of device-resident synthetic 
       reference torch_darktable/pipeline/config.py:114-146; "nlmeans" in BASELINE.json has no
       counterpart in the reference, its denoiser is the tiled-FFT Wiener filter)
   rcd (configs[1]): one 4096x3072 fp32 frame through RCD.process.
+The frames of a batch are independent; they are issued round-robin on --streams HIP streams (default 2), each with
+its own op workspaces, so one frame's kernel tails overlap the next frame's kernels.
 
 Multi-GPU (BASELINE.json configs[3]): one process per GPU.  Frames are independent, so every rank
 processes its own batch on its own stream -- weak scaling, NO collective on the data path and no
@@ -66,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument('--workload', choices=['isp', 'rcd'], default='isp')
     ap.add_argument('--storage', choices=['f16', 'f32'], default=None, help='image storage type (default: f16 for isp, f32 for rcd)')
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 8 for isp, 1 for rcd)')
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
     ap.add_argument('--width', type=int, default=W12)
     ap.add_argument('--height', type=int, default=H12)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -327,9 +330,10 @@ def main(argv=None):
 
     world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    if torch.cuda.device_count() <= local_rank:
+    shared = os.environ.get('TDK_BENCH_SHARE_GPU') == '1'   # rehearsal of the rank protocol on a box with fewer GPUs than ranks
+    if torch.cuda.device_count() <= local_rank and not shared:
         raise SystemExit(f'bench.py: rank {rank} needs cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible')
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', local_rank % torch.cuda.device_count() if shared else local_rank)
     torch.cuda.set_device(dev)
 
     import __graft_entry__
@@ -342,16 +346,31 @@ def main(argv=None):
     storage = args.storage or ('f16' if args.workload == 'isp' else 'f32')
     frames = args.frames or (8 if args.workload == 'isp' else 1)
     w, h = args.width, args.height
-    dtype, process = build_pipeline(td, dev, w, h, storage, args.workload)
+    # The frames of a batch are independent: they are issued round-robin on `nstreams` HIP streams, each with its own
+    # op workspaces, so that the tail of one frame's kernels (partially filled last rounds, 1-workgroup finish kernels)
+    # overlaps the next frame's -- measured +13 % at 2-3 streams (profiles/streams_exp.py).
+    nstreams = max(1, min(args.streams, frames))
+    pipes = [build_pipeline(td, dev, w, h, storage, args.workload) for _ in range(nstreams)]
+    dtype, process = pipes[0]
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(dev)]
 
     # device-resident synthetic inputs, per-frame seeds 1234 + i (distinct per rank)
     inputs = [synthetic_bayer(h, w, seed=1234 + rank * frames + i, device=dev).to(dtype) for i in range(frames)]
     torch.cuda.synchronize()
 
-    def step():
+    def step_serial():  # every frame on the current stream: the per-kernel table comes from this
         out = None
         for b in inputs:
             out = process(b)
+        return out
+
+    def step():
+        if nstreams == 1:
+            return step_serial()
+        out = None
+        for i, b in enumerate(inputs):
+            with torch.cuda.stream(streams[i % nstreams]):
+                out = pipes[i % nstreams][1](b)
         return out
 
     for _ in range(args.warmup):
@@ -365,7 +384,7 @@ def main(argv=None):
     table, dom = {}, None
     if use_timer:
         _native.profile_enable(True)
-        step()
+        step_serial()
         torch.cuda.synchronize()
         table = _native.profile_report()
         _native.profile_enable(False)
@@ -428,6 +447,9 @@ def main(argv=None):
             'frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None, 'traffic': traffic, 'traffic_captured_at_git': captured_at,
             'measured_traffic_GBps': round(traffic / avg_s / 1e9, 1) if traffic else None,
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches': cnt, 'algorithmic_bytes_per_launch': int(bpp * w * h) if bpp else None,
+            # the same kernel with the GPU to itself (untimed serial pass): in the timed region frames on the other stream(s) share the CUs with it
+            'avg_launch_us_alone': round(table[dom][1] / table[dom][0] * 1e3, 2),
+            'frac_alone': round(bpp * w * h / (table[dom][1] / table[dom][0] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if bpp else None,
             'kernel_launches_in_timed_region': launches_total, 'valu': valu,
         }
     # whole-pipeline roofline at the Python-wrapper stage boundaries (41 B/px f16, 79 B/px f32; RCD only: 4*s B/px)
@@ -443,15 +465,17 @@ def main(argv=None):
             'workload': ('12 MP full pipeline (RCD -> Wiener log-L sigma=0.075 K=32 ov=4 -> bilateral sigma_s=2 sigma_r=0.2 detail=0.4 -> '
                          'metrics -> Reinhard gamma=0.75 intensity=2 light_adapt=1 -> u8), batch 8 per GPU') if args.workload == 'isp'
                         else '12 MP RCD demosaic, single frame',
-            'width': w, 'height': h, 'frames_per_gpu_per_step': frames, 'storage': storage, 'arithmetic': 'f32',
-            'denoiser': 'Wiener (the reference has no nlmeans)', 'sharding': 'independent frames per GPU, no collective (gloo barrier + max of the timing only)',
+            'width': w, 'height': h, 'frames_per_gpu_per_step': frames, 'streams_per_gpu': nstreams, 'storage': storage, 'arithmetic': 'f32',
+            'denoiser': 'Wiener (the reference has no nlmeans)', 'sharding': 'independent frames per GPU, no collective (gloo barrier + max of the timing only)'
+            + (' -- REHEARSAL: ranks share GPUs (TDK_BENCH_SHARE_GPU=1), not a scaling measurement' if shared else ''),
         },
         'ranks_ran': len(per_rank),
         'per_rank_MPps': [round(frames * args.steps * mp_per_frame / t, 1) for t in per_rank],
         'pipeline_roofline': {'algorithmic_bytes_per_px': pipe_bpp, 'achieved_GBps_per_gpu': round(pipe_gbs, 2), 'frac_of_8TBps': round(pipe_gbs / HBM_PEAK_GBS, 5)},
         'roofline': roofline,
         'kernel_ms_per_frame': stage_ms,
-        'kernel_ms_per_frame_source': 'one untimed step with every launch bracketed by events; the roofline kernel is timed live in the timed region',
+        'kernel_ms_per_frame_source': 'one untimed step, frames back to back on one stream, every launch bracketed by events; the roofline kernel is '
+                                      'timed live in the timed region (where frames on other streams share the GPU with it)',
         'git': _git_head(),
     }
     if world == 1 and not args.no_cpu_baseline:
