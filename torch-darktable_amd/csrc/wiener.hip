@@ -395,6 +395,24 @@ __device__ __forceinline__ float fold4(const float* __restrict__ row0, const flo
   return v;
 }
 
+// The same fold for four consecutive pixels x0 .. x0 + 3 with (x0 + u0) % 4 == 0 when s % 4 == 0: group width, overlap
+// and pixel offset are then multiples of 4, so the four pixels sit in the same slabs at a 16-B aligned offset -- one
+// 16-B load per slab instead of four scattered 4-B loads (the per-pixel form made the finish kernels
+// texture-addresser bound).  Same values, same order of additions per pixel.
+__device__ __forceinline__ float4 fold4x4(const float* __restrict__ row0, const float* __restrict__ row1, int x0, int u0, const Geom& g, size_t slab_sz) {
+  const AxisPos px = axis_pos(x0 + u0, g.BSX, g.magic_x, g.K - g.s);
+  auto at = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+  auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  float4 v = at(row0 + px.grp * slab_sz + px.off);
+  if (px.prev) add(v, at(row0 + (px.grp - 1) * slab_sz + px.off + g.BSX));
+  if (row1) {
+    add(v, at(row1 + px.grp * slab_sz + px.off));
+    if (px.prev) add(v, at(row1 + (px.grp - 1) * slab_sz + px.off + g.BSX));
+  }
+  return v;
+}
+__device__ __forceinline__ bool fold_vec_ok(const float* slabs, const Geom& g) { return (g.s & 3) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0; }
+
 struct RowPtrs {
   const float *row0, *row1;
   float my;
@@ -436,18 +454,27 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
   const int u0 = -g.jmin * g.s;
   const size_t slab_sz = (size_t)g.RSXP * g.RSY;
   const int ngroup = W / VEC;  // VEC == 4 requires W % 4 == 0: a group never straddles a row
+  const bool vfold = fold_vec_ok(slabs, g);
   for (int y = blockIdx.y; y < H; y += gridDim.y) {
     const RowPtrs rp = row_ptrs(slabs, y, u0, g, slab_sz, prm);
     for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
       const int x0 = gi_ * VEC;
       const size_t gi = (size_t)y * ngroup + gi_;
-      float v[3 * VEC], l[VEC];
+      float v[3 * VEC], l[VEC], accs[VEC];
       if constexpr (VEC == 4) rgb4_io<T>::load(rgb, gi, v);
       else { v[0] = ld(rgb, gi * 3); v[1] = ld(rgb, gi * 3 + 1); v[2] = ld(rgb, gi * 3 + 2); }
+      if (VEC == 4 && vfold) {
+        const float4 a4 = fold4x4(rp.row0, rp.row1, x0, u0, g, slab_sz);
+        accs[0] = a4.x;
+        if constexpr (VEC == 4) { accs[1] = a4.y; accs[2] = a4.z; accs[3] = a4.w; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) accs[k] = fold4(rp.row0, rp.row1, x0 + k, u0, g, slab_sz);
+      }
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
         const int x = x0 + k;
-        const float acc = fold4(rp.row0, rp.row1, x, u0, g, slab_sz);
+        const float acc = accs[k];
         const float mask = prm.m1[x & (g.s - 1)] * rp.my;
         const f3 r = cA::modify_log_luminance(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), acc * __builtin_amdgcn_rcpf(mask + 1e-15f));
         v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
@@ -477,12 +504,27 @@ __global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ 
     for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
       const size_t gi = (size_t)y * ngroup + gi_;
       float v[3 * VEC];
+      if (VEC == 4 && fold_vec_ok(slabs, g) && (chan_sz & 3) == 0) {
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        const int x = gi_ * VEC + k;
-        const float rnorm = __builtin_amdgcn_rcpf(prm.m1[x & (g.s - 1)] * rp.my + 1e-15f);
+        for (int c = 0; c < 3; c++) {
+          const float4 a4 = fold4x4(rp.row0 + c * chan_sz, rp.row1 ? rp.row1 + c * chan_sz : nullptr, gi_ * VEC, u0, g, slab_sz);
+          v[c] = a4.x;
+          if constexpr (VEC == 4) { v[3 + c] = a4.y; v[6 + c] = a4.z; v[9 + c] = a4.w; }
+        }
 #pragma unroll
-        for (int c = 0; c < 3; c++) v[3 * k + c] = fold4(rp.row0 + c * chan_sz, rp.row1 ? rp.row1 + c * chan_sz : nullptr, x, u0, g, slab_sz) * rnorm;
+        for (int k = 0; k < VEC; k++) {
+          const float rnorm = __builtin_amdgcn_rcpf(prm.m1[(gi_ * VEC + k) & (g.s - 1)] * rp.my + 1e-15f);
+#pragma unroll
+          for (int c = 0; c < 3; c++) v[3 * k + c] *= rnorm;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const int x = gi_ * VEC + k;
+          const float rnorm = __builtin_amdgcn_rcpf(prm.m1[x & (g.s - 1)] * rp.my + 1e-15f);
+#pragma unroll
+          for (int c = 0; c < 3; c++) v[3 * k + c] = fold4(rp.row0 + c * chan_sz, rp.row1 ? rp.row1 + c * chan_sz : nullptr, x, u0, g, slab_sz) * rnorm;
+        }
       }
       if constexpr (VEC == 4) rgb4_io<T>::store(out, gi, v);
       else { st(out, gi * 3, v[0]); st(out, gi * 3 + 1, v[1]); st(out, gi * 3 + 2, v[2]); }
