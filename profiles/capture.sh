@@ -13,6 +13,8 @@ export TMPDIR=/tmp
 python3 bench.py --steps 10 --warmup 3 > $OUT/bench_isp_plain.json 2> $OUT/bench_isp_plain.err || exit 1
 python3 bench.py --workload rcd --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rcd_plain.json 2> $OUT/bench_rcd_plain.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_isp_under_rocprof.json 2> $OUT/rocprof_stats.err || exit 1
+# the same command with the frames back to back on one stream: per-kernel durations with the GPU to themselves
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench -- python3 bench.py --steps 5 --warmup 2 --streams 1 --no-cpu-baseline > $OUT/bench_isp_streams1_under_rocprof.json 2> $OUT/rocprof_stats1.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/valu -o v -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_valu.log 2>&1 || exit 1
