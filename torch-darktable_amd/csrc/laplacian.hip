@@ -143,18 +143,16 @@ __device__ __forceinline__ float gamma_centre(int k) { return ((float)k + 0.5f) 
 
 // ---------------------------------------------------------------- level 0 -> level 1, all seven pyramids
 // A 512-thread workgroup owns 32 x 16 level-1 cells.  Phase 1: the (2*32+3) x (2*16+3) level-0 window, input and
-// six curves, rounded to binary16 into LDS.  Phase 2: horizontal 5-tap sums at the tile's coarse columns.  Phase
-// 3: vertical combination and store (9 + 9 instead of 25 multiply-adds per output; the summation order differs
-// from the 2-D form -- far below the binary16 rounding of the result).  A window that lies inside a padding band
-// holds one distinct column (left / right band), one distinct row (top / bottom) or one sample (corners): only
-// those are evaluated, and phases 2 / 3 read them through the same index map, i.e. run the same arithmetic on
-// the same values as the full window would.
+// six curves, rounded to binary16 into LDS.  Phase 2: horizontal 5-tap sums at the tile's coarse columns, then their
+// vertical combination and store (separable: the summation order differs from the 2-D form -- far below the
+// binary16 rounding of the result).  A window that lies inside a padding band holds one distinct column (left / right
+// band), one distinct row (top / bottom) or one sample (corners): only those are evaluated, and phase 2 reads them
+// through the same index map, i.e. runs the same arithmetic on the same values as the full window would.
 constexpr int A_TW = 32, A_TH = 16, A_FW = 2 * A_TW + 3, A_FH = 2 * A_TH + 3, A_FS = A_FW + 1, A_NT = 512;
 
 template <bool HAS_CLARITY>
 __global__ __launch_bounds__(A_NT) void level1_kernel(const float* __restrict__ in, Layout L, float sigma, float shadows, float highlights, float clarity) {
   __shared__ __half fine[NP][A_FH * A_FS];
-  __shared__ float hrow[NP][A_FH * A_TW];
   const CurveK ck = make_curve(sigma, shadows, highlights, clarity);
   const int cw = L.lw(1), ch = L.lh(1);
   const int CX0 = blockIdx.x * A_TW, CY0 = blockIdx.y * A_TH;
@@ -174,34 +172,53 @@ __global__ __launch_bounds__(A_NT) void level1_kernel(const float* __restrict__ 
     for (int k = 0; k < NG; k++) fine[1 + k][r * A_FS + c] = __float2half_rn(curve<HAS_CLARITY>(v, gamma_centre(k), ck));
   }
   __syncthreads();
+  // Phase 2: thread = (coarse column, pyramid, upper / lower 8 rows of the tile).  It forms the horizontal 5-tap sums of
+  // the 19 window rows behind its 8 outputs once, in registers, and combines them vertically -- no second LDS array
+  // (the workgroup's LDS is the 33 KB window: four workgroups per CU) and no second barrier.
   const float w5[5] = {1.0f / 16.0f, 4.0f / 16.0f, 6.0f / 16.0f, 4.0f / 16.0f, 1.0f / 16.0f};
-  const int ncc = one_col ? 1 : A_TW;  // distinct coarse columns
-  for (int i = threadIdx.x; i < NP * nrow * ncc; i += A_NT) {
-    const int pxl = one_col ? 0 : (i & (A_TW - 1)), kr = one_col ? i : i / A_TW;
-    const int k = one_row ? kr : kr / A_FH, r = one_row ? 0 : kr - k * A_FH;
-    const int px = min(CX0 + pxl, cw - 1);
-    const int c0 = one_col ? 0 : 2 * clampc(px, cw) - fx0;
-    const __half* row = &fine[k][r * A_FS];
-    float acc = 0.0f;
-    if (one_col) {  // five equal taps, same instructions as below
+  const int item = threadIdx.x;
+  if (item >= A_TW * 2 * NP) return;
+  const int pxl = item & (A_TW - 1), hk = item / A_TW, half = hk & 1, k = hk >> 1;
+  const int px = CX0 + pxl;
+  if (px >= cw) return;
+  const int c0 = one_col ? 0 : 2 * clampc(px, cw) - fx0;  // even; the rows start 4-B aligned: two aligned dwords + one half per row
+  auto hsum = [&](int r) {  // horizontal sum of window row r at this column
+    const __half* row = &fine[k][(one_row ? 0 : r) * A_FS];
+    if (one_col) {  // five equal taps, same instructions as the general case
       const __half same[6] = {row[0], row[0], row[0], row[0], row[0], row[0]};
-      acc = dot5(same, 1.0f, 0.0f);
-    } else {
-      acc = dot5(row + c0 - 2, 1.0f, 0.0f);  // c0 is even and the rows start 4-B aligned: two aligned dwords + one half
+      return dot5(same, 1.0f, 0.0f);
     }
-    hrow[k][r * A_TW + pxl] = acc;
-  }
-  __syncthreads();
-  const int pxl = threadIdx.x & (A_TW - 1);
-  const int px = CX0 + pxl, py = CY0 + threadIdx.x / A_TW;
-  if (px >= cw || py >= ch) return;
-  const int ly = 2 * clampc(py, ch) - fy0;
+    return dot5(row + c0 - 2, 1.0f, 0.0f);
+  };
+  __half* dst = L.chain(k, 1);
+  const int PY0 = CY0 + 8 * half;
+  if (CY0 >= 1 && PY0 + 7 <= ch - 2) {  // no centre clamp in this half: output o reads window rows 16 half + 2 o .. + 4
+    float hv[19];
+    if (one_row) {
+      const float v = hsum(0);
 #pragma unroll
-  for (int k = 0; k < NP; k++) {
-    float acc = 0.0f;
+      for (int i = 0; i < 19; i++) hv[i] = v;
+    } else {
 #pragma unroll
-    for (int j = -2; j <= 2; j++) acc += hrow[k][(one_row ? 0 : ly + j) * A_TW + (one_col ? 0 : pxl)] * w5[j + 2];
-    hst(L.chain(k, 1), px, py, cw, acc);
+      for (int i = 0; i < 19; i++) hv[i] = hsum(16 * half + i);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc += hv[2 * o + j] * w5[j];
+      hst(dst, px, PY0 + o, cw, acc);
+    }
+  } else {  // first / last tile rows of the level
+    for (int o = 0; o < 8; o++) {
+      const int py = PY0 + o;
+      if (py >= ch) break;
+      const int ly = 2 * clampc(py, ch) - fy0;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = -2; j <= 2; j++) acc += hsum(ly + j) * w5[j + 2];
+      hst(dst, px, py, cw, acc);
+    }
   }
 }
 
