@@ -26,6 +26,19 @@
 
 #include "tdk_color.h"
 
+#ifdef TDK_BIL_TIMING
+// experiments: clock64() deltas per phase of one workgroup of the tile kernel (profiles/bilateral_phase_exp.py)
+__device__ unsigned long long g_bil_phase_cycles[16];
+#define BIL_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == 1000) { const unsigned long long t_ = clock64(); atomicAdd(&g_bil_phase_cycles[k], t_ - bil_t0); bil_t0 = t_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int tdk_debug_bilateral_phase_cycles(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bil_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_bil_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define BIL_MARK(k)
+#endif
+
 namespace {
 
 struct GridDims {
@@ -313,6 +326,9 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
                                                             int height, GridDims d, float sigma_s, float sigma_r, float detail, int tiles_x,
                                                             int ntiles, TileLds L) {
   extern __shared__ float smem[];
+#ifdef TDK_BIL_TIMING
+  unsigned long long bil_t0 = clock64();
+#endif
   float* A = smem;                      // [sz][plane] grid, cell (lx, ly) at ly * RS + lx
   float* U = A + d.sz * L.plane;        // z sample coordinate of every pixel of the tile + halo, then blur temp
   float* gxs = U + L.usize;             // x sample coordinate of pixel column p_lo + i
@@ -353,18 +369,37 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
       if (k == 0) first[l] = a;
     }
   };
+  BIL_MARK(6);
   axis_tables(ax, width, d.sx, WX, xa_t);
   axis_tables(ay, height, d.sy, WY, ya_t);
+  BIL_MARK(7);
   {
     const float inv_np = 1.0f / (float)ax.np;
     const TL* src = lum + (size_t)ay.p_lo * width + ax.p_lo;
-    for (int i = tid; i < ax.np * ay.np; i += FNT) {
-      const int r = fast_div(i, inv_np), c = i - r * ax.np;
-      U[i] = clampf(div_by(ld(src, (size_t)(r * width + c)), sigma_r, rc_r), 0.0f, ztop);  // make_sample's gz
+    // all loads of a thread first, then the arithmetic: a loop of load -> use pays the global latency once per iteration
+    // (measured: this phase was 30 % of the workgroup's time with one exposed latency per sample)
+    constexpr int BATCH = 6;
+    const int total = ax.np * ay.np;
+    for (int base = tid; base < total; base += BATCH * FNT) {
+      float v[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; k++) {
+        const int i = base + k * FNT;
+        const int r = fast_div(i, inv_np), c = i - r * ax.np;
+        v[k] = (i < total) ? ld(src, (size_t)(r * width + c)) : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; k++) {
+        const int i = base + k * FNT;
+        if (i < total) U[i] = clampf(div_by(v[k], sigma_r, rc_r), 0.0f, ztop);  // make_sample's gz
+      }
     }
   }
+  BIL_MARK(8);
   for (int i = tid; i < d.sz * PS; i += FNT) A[i] = 0.0f;
+  BIL_MARK(9);
   __syncthreads();
+  BIL_MARK(0);
 
   // ---- splat (gather, raster order per column; same expressions as splat_gather_kernel)
   const float contrib = 1.0f / (sigma_s * sigma_s);
@@ -398,9 +433,11 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
     }
   }
   __syncthreads();
+  BIL_MARK(1);
 
   // ---- blur x: A -> U, one thread per (z, row) with a register window (cells beyond the LDS tile
-  // read as zero; they only feed cells nobody slices)
+  // read as zero; they only feed cells nobody slices).  (Cutting the rows into segments for more threads, or
+  // prefetching four cells, did not shorten this phase: its LDS reads queue behind the other workgroups' splats.)
   const float w0 = 6.0f / 16.0f, w1 = 4.0f / 16.0f, w2 = 1.0f / 16.0f;
   {
     const float inv_ncy = 1.0f / (float)ay.nc;
@@ -417,7 +454,8 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
     }
   }
   __syncthreads();
-  // ---- blur y: U -> A, one thread per (z, column)
+  BIL_MARK(2);
+  // ---- blur y: U -> A, one thread per (z, column), four reads in flight (the column walk strides over whole rows)
   {
     const float inv_ncx = 1.0f / (float)ax.nc;
     for (int cc = tid; cc < d.sz * ax.nc; cc += FNT) {
@@ -425,14 +463,20 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
       const float* p = U + z * PS + lx;
       float* q = A + z * PS + lx;
       float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[RS];
-      for (int ly = 0; ly < ay.nc; ly++) {
-        const float p2 = (ly + 2 < ay.nc) ? p[(ly + 2) * RS] : 0.0f;
-        q[ly * RS] = c0 * w0 + w1 * (p1 + m1) + w2 * (p2 + m2);
-        m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+      for (int ly0 = 0; ly0 < ay.nc; ly0 += 4) {
+        float nx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nx[k] = (ly0 + k + 2 < ay.nc) ? p[(ly0 + k + 2) * RS] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (ly0 + k < ay.nc) q[(ly0 + k) * RS] = c0 * w0 + w1 * (p1 + m1) + w2 * (nx[k] + m2);
+          m2 = m1; m1 = c0; c0 = p1; p1 = nx[k];
+        }
       }
     }
   }
   __syncthreads();
+  BIL_MARK(3);
   // ---- z derivative, in place (register window), one thread per column
   for (int c = tid; c < RS * ay.nc; c += FNT) {
     float* p = A + c;
@@ -446,6 +490,7 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
     }
   }
   __syncthreads();
+  BIL_MARK(4);
 
   // ---- slice (+ put the new lightness back into the pixel)
   const float norm = -detail * sigma_r * 4.0f;
@@ -496,6 +541,7 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
       else { st(out, i0 * 3, o[0]); st(out, i0 * 3 + 1, o[1]); st(out, i0 * 3 + 2, o[2]); }
     }
   }
+  BIL_MARK(5);
 }
 
 constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;  // two workgroups per CU
