@@ -421,7 +421,7 @@ def test_wiener_log_luminance_pipeline(td, oracle, dev, scene, size):
     assert np.abs(got - npy(chain)).max() < 2e-6
 
 
-@pytest.mark.parametrize('size', [(120, 161), (4, 4), (7, 9), (16, 16), (33, 70), (256, 200), (301, 515), (600, 1100)])
+@pytest.mark.parametrize('size', [(120, 161), (4, 4), (7, 9), (16, 16), (33, 70), (256, 200), (301, 515), (600, 1100), (5, 301), (1000, 9), (64, 2050)])
 def test_laplacian_level_schedules(td, oracle, dev, scene, size):
     """Image sizes that take every branch of the launch schedule in csrc/laplacian.hip: two levels only, everything
     inside the single-workgroup kernels, a single reduce launch, a reduce pair, tiled assembles."""
