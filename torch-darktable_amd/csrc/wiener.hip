@@ -121,11 +121,11 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <int K, bool INV> __device__ __forceinline__ void transpose_lds(float (&v)[K], float* buf, int slot, int row, int col) {
-  constexpr int ST = K + 1;
   // forward: write [row][k], read [k][col];  inverse: write [k][col], read [row][k]   (col = lane_freq(row))
-  const int wbase = INV ? col : row * ST, rbase = INV ? row * ST : col;
-  constexpr int WS = INV ? ST : 1, RS = INV ? 1 : ST;
   if constexpr (K == 16) {
+    constexpr int ST = K + 1;
+    const int wbase = INV ? col : row * ST, rbase = INV ? row * ST : col;
+    constexpr int WS = INV ? ST : 1, RS = INV ? 1 : ST;
     float* my = buf + slot * (K * ST);
 #pragma unroll
     for (int k = 0; k < K; k++) my[wbase + k * WS] = v[k];
@@ -134,16 +134,33 @@ template <int K, bool INV> __device__ __forceinline__ void transpose_lds(float (
     for (int k = 0; k < K; k++) v[k] = my[rbase + k * RS];
     wave_fence();
   } else {
+    // K = 32: the two slots take turns in one 32 x TST buffer.  The side on which a lane walks its own row is
+    // contiguous: 16-B accesses there (row stride 36 floats = 9 x 16 B: the eight lanes of a ds_*_b128 group hit eight
+    // different 4-bank slots), 4-B accesses on the column side (lanes on consecutive columns).
+    constexpr int ST = 36;
 #pragma unroll
     for (int sl = 0; sl < 2; sl++) {
       if (slot == sl) {
+        if constexpr (!INV) {
 #pragma unroll
-        for (int k = 0; k < K; k++) buf[wbase + k * WS] = v[k];
+          for (int k = 0; k < K; k += 4) *reinterpret_cast<float4*>(buf + row * ST + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; k++) buf[k * ST + col] = v[k];
+        }
       }
       wave_fence();
       if (slot == sl) {
+        if constexpr (!INV) {
 #pragma unroll
-        for (int k = 0; k < K; k++) v[k] = buf[rbase + k * RS];
+          for (int k = 0; k < K; k++) v[k] = buf[k * ST + col];
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(buf + row * ST + k);
+            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+          }
+        }
       }
       wave_fence();
     }
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
   constexpr int SH = EM >= 32 ? 0 : (EM == 16 ? 1 : (EM == 8 ? 2 : 3));  // rows that share the 32 banks
   constexpr int FLUSH = (CAR + EM - 1) / EM;
   // Per-wave LDS region: the transposition buffer during a step, then the wave's EM finished columns for the fold.
-  constexpr int TBUF = (K == 16) ? 4 * 16 * 17 : 32 * 33, EBLK = TPW * K * EM;
+  constexpr int TBUF = (K == 16) ? 4 * 16 * 17 : 32 * 36, EBLK = TPW * K * EM;
   constexpr int REG = ((TBUF > EBLK ? TBUF : EBLK) + 3) & ~3;
   constexpr int NBUF = (2 * REG * 4 * 16 <= 160 * 1024) ? 2 : 1;  // two regions (one barrier per step) if 16 waves still fit a CU
   __shared__ __align__(16) float lds[NBUF * NWV * REG];
