@@ -112,8 +112,8 @@ __device__ __forceinline__ void partner2(float& a, float& b, unsigned long long 
 
 // Transpose the K x K tile each slot holds one row per lane through a wave-private LDS buffer (LDS operations
 // of one wave execute in issue order, so only compiler fences are needed, no barrier).  K = 16: the four
-// slots of the wave go at once (4 x 16 x 17 floats); K = 32: the two slots take turns in one 32 x 33 buffer --
-// half the footprint, and a half-active wave's ds_read/write_b32 costs half the LDS cycles.  The read side
+// slots of the wave go at once (4 x 16 x 17 floats); K = 32: the two slots take turns in one 32 x 36 buffer --
+// half the footprint, and a half-active wave's LDS access costs half the LDS cycles.  The read side
 // applies the frequency -> lane assignment for free: lane l reads column lane_freq(l).
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
