@@ -23,9 +23,18 @@ constexpr int TW = 64, TH = 32;
 constexpr int PNT = 512;                    // threads per workgroup: 4 workgroups x 8 waves per CU (LDS 39 KB each)
 constexpr int RH = 4;                       // raw halo: 1 (red/blue) + 3 (green)
 constexpr int RW_ = TW + 2 * RH, RHT = TH + 2 * RH;   // 72 x 40
-constexpr int RS = RW_ + 1;                 // padded LDS row stride
 constexpr int GW = TW + 2, GH = TH + 2;     // 66 x 34 intermediate region
-constexpr int GS = GW + 1;
+// LDS layouts, chosen for the lane strides of the phases (b32 accesses of lanes 2 or 4 columns apart are 2- / 4-way
+// bank conflicts in a row-major tile: measured 58 % of this kernel's LDS cycles):
+//   raw tile: even columns, then odd columns of a row -- the green phase walks one CFA class, i.e. every other column;
+//   intermediate planes: columns de-interleaved by 4 -- the red/blue phase gives a lane 4 consecutive pixels.
+// With these, consecutive lanes touch consecutive words in both phases.  Row stride 72 in both (== 8 mod 32: the
+// 16-lane halves of a wave that sit two rows apart in the last phase land on disjoint banks); 40 896 B in all, so four
+// workgroups still share a CU.
+constexpr int RS = RW_, RHALF = RW_ / 2;    // raw: row stride 72, odd columns start at +36
+constexpr int GS = 72, GQ = 17;             // planes: row stride 72, quarter q (= column mod 4) starts at + 17 q
+__device__ __forceinline__ int raw_at(int r, int c) { return r * RS + (c >> 1) + (c & 1) * RHALF; }
+__device__ __forceinline__ int pln_at(int r, int c) { return r * GS + (c >> 2) + (c & 3) * GQ; }
 
 // One 64 x 32 tile.  INTERIOR = the tile, its 1-px intermediate ring and its 4-px raw halo stay at least
 // 3 px inside the image: no in-image tests, no 3x3 border-average path.
@@ -51,7 +60,7 @@ __device__ __forceinline__ void ppg_tile(const T* __restrict__ src, const T* __r
     for (int k = 0; k < NLD; k++) {
       const int i = threadIdx.x + k * PNT;
       const int r = i / RW_, c = i - r * RW_;
-      if (i < RW_ * RHT) raw[r * RS + c] = tmp[k];
+      if (i < RW_ * RHT) raw[raw_at(r, c)] = tmp[k];
     }
   }
   __syncthreads();
@@ -60,19 +69,22 @@ __device__ __forceinline__ void ppg_tile(const T* __restrict__ src, const T* __r
   // lane of a wave sits on the same kind of site: the green interpolation at red/blue sites runs
   // with all lanes active instead of under a checkerboard mask, and green sites only copy.
   constexpr int CW = GW / 2, CH = GH / 2;  // 33 x 17 sites per class
-  for (int cls = 0; cls < 4; cls++) {
+#pragma unroll
+  for (int cls = 0; cls < 4; cls++) {  // unrolled: the column parity of a class decides which half of a raw row a tap reads
     const int rp = cls >> 1, cp = cls & 1;
     const int cc = cfa_color(y0 - 1 + rp, x0 - 1 + cp, pattern);  // CFA colour of the whole class (scalar: x0, y0 are even)
     for (int i = threadIdx.x; i < CW * CH; i += PNT) {
-      const int rr = i / CW, r = 2 * rr + rp, c = 2 * (i - rr * CW) + cp;
+      const int rr = i / CW, ci = i - rr * CW, r = 2 * rr + rp, c = 2 * ci + cp;
       const int gx = x0 - 1 + c, gy = y0 - 1 + r;
       f3 v = mk3(0.0f, 0.0f, 0.0f);
       if (INTERIOR || (gx >= 0 && gy >= 0 && gx < width && gy < height)) {
         if (!INTERIOR && (gx < 3 || gy < 3 || gx >= width - 3 || gy >= height - 3)) {
           v = border_average([&](int xx, int yy) { return ld(orig, (size_t)yy * width + xx); }, gx, gy, width, height, pattern);
         } else {
-          const float* ctr = raw + (r + RH - 1) * RS + (c + RH - 1);
-          const float pc = ctr[0];
+          // raw column c + RH - 1 + d = 2 ci + (cp + RH - 1 + d): half and offset inside it are compile-time per tap
+          const float* rrow = raw + (r + RH - 1) * RS + ci;
+          auto tap = [&](int d, int dr) { const int k = cp + RH - 1 + d; return rrow[dr * RS + (k >> 1) + (k & 1) * RHALF]; };
+          const float pc = tap(0, 0);
           if (cc == 0) v.x = pc;
           else if (cc == 2) v.z = pc;
           else v.y = pc;
@@ -80,17 +92,17 @@ __device__ __forceinline__ void ppg_tile(const T* __restrict__ src, const T* __r
             float h[7], vv[7];
 #pragma unroll
             for (int d = -3; d <= 3; d++) {
-              h[d + 3] = ctr[d];
-              vv[d + 3] = ctr[d * RS];
+              h[d + 3] = tap(d, 0);
+              vv[d + 3] = tap(0, d);
             }
             v.y = ppg_green(h, vv);
           }
           v = mk3(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f));
         }
       }
-      pr[r * GS + c] = v.x;
-      pg[r * GS + c] = v.y;
-      pb[r * GS + c] = v.z;
+      pr[pln_at(r, c)] = v.x;
+      pg[pln_at(r, c)] = v.y;
+      pb[pln_at(r, c)] = v.z;
     }
   }
   __syncthreads();
@@ -107,10 +119,13 @@ __device__ __forceinline__ void ppg_tile(const T* __restrict__ src, const T* __r
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int gx = x + k;
-      const int base = (ly + 1) * GS + (lx + k + 1);
+      // plane column lx + k + 1 + dx with lx a multiple of 4: quarter and offset inside it are compile-time per (k, dx)
+      const int rowb = (ly + 1) * GS + (lx >> 2);
+      auto at = [&](int dx, int dy) { const int kk = k + 1 + dx; return rowb + dy * GS + (kk >> 2) + (kk & 3) * GQ; };
+      const int base = at(0, 0);
       f3 col = mk3(pr[base], pg[base], pb[base]);
       if (INTERIOR || (gx < width && !(gx == 0 || y == 0 || gx == width - 1 || y == height - 1))) {
-        auto nb = [&](int dx, int dy) { const int q = base + dy * GS + dx; return mk3(pr[q], pg[q], pb[q]); };
+        auto nb = [&](int dx, int dy) { const int q = at(dx, dy); return mk3(pr[q], pg[q], pb[q]); };
         col = ppg_redblue(nb, col, cfa_color(yu, k, pattern), cfa_color(yu, k + 1, pattern) == 0);  // x0 + lx is a multiple of 4
       }
       px[3 * k] = fmaxf(col.x, 0.0f);
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(PNT) void ppg_fused(const T* __restrict__ src, cons
                                                  int height, uint32_t pattern, int vec_ok) {
   __shared__ float raw[RHT * RS];
   __shared__ float pr[GH * GS], pg[GH * GS], pb[GH * GS];
+  static_assert((RHT * RS + 3 * GH * GS) * sizeof(float) <= 40 * 1024, "four workgroups per CU");
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const bool interior = x0 >= 8 && y0 >= 8 && x0 + TW + 8 <= width && y0 + TH + 8 <= height;
   if (interior) ppg_tile<T, true>(src, orig, out, width, height, pattern, vec_ok, raw, pr, pg, pb);
