@@ -76,3 +76,21 @@ def test_shard_range_properties():
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_frame_streams_single_stream_is_a_plain_loop():
+    """FrameStreams with one stream touches no HIP API: the frames go through one chain object in order."""
+    from torch_darktable.sharding import FrameStreams
+
+    made = []
+
+    def make():
+        made.append(1)
+        return lambda f: f * 2
+
+    runner = FrameStreams(None, make, streams=1)
+    assert runner.run([1, 2, 3]) == [2, 4, 6] and len(made) == 1
+    import pytest
+
+    with pytest.raises(ValueError):
+        FrameStreams(None, make, streams=0)
