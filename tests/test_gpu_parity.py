@@ -196,6 +196,24 @@ def test_rcd_division_flavours_bit_exact(td, oracle, dev, scene, case):
         assert np.isfinite(got).all()
 
 
+def test_rcd_fp16_extremes_stay_on_the_exact_path(td, oracle, dev, scene):
+    """binary16 storage spans exactly the sample range of the fast division flavour (smallest subnormal 2^-24, largest
+    finite 65504 < 2^16): extreme but representable samples must still give the oracle's bits (fp32 math, one rounding
+    at the store)."""
+    h, w = 320, 384
+    b16 = oracle.mosaic(scene(h, w, 23), oracle.RGGB)[:, :, 0].astype(np.float16)
+    b16[100:104, 100:140] = np.float16(5.96e-8)      # 2^-24
+    b16[200:203, 90:300] = np.float16(65504.0)
+    b16[250:260:2, 200:240:2] = np.float16(0.0)
+    b16 = np.ascontiguousarray(b16[:, :, None])
+    got = npy(td.RCD(dev, (w, h), td.BayerPattern.RGGB).process(gpu(b16, dev)))
+    with np.errstate(all='ignore'):
+        ref = oracle.rcd(b16.astype(np.float32), oracle.RGGB).astype(np.float16)
+    assert got.dtype == np.float16
+    same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), f'{(~same).sum()} mismatches, first at {np.argwhere(~same)[:5].tolist()}'
+
+
 def test_rcd_rejects_odd_width_and_wrong_shape(td, dev):
     ws = td.RCD(dev, (64, 32), td.BayerPattern.RGGB)
     with pytest.raises(RuntimeError):
