@@ -629,9 +629,9 @@ template <int K> WParams make_params(const Geom& g, int ov) {
 
 template <typename T, int K, int OV>
 int launch_tiles_ov(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, const WParams& prm, hipStream_t st_, int nplanes) {
-  // 16-B row loads: planar rows need W and s in whole vectors; interleaved RGB rows are read 4 pixels at a time
-  const int vec_ok = tdk_aligned(in, 16) && (C == 1 ? (W % (16 / (int)sizeof(T)) == 0) && (g.s % (16 / (int)sizeof(T)) == 0)
-                                                    : (C == 3 && W % 4 == 0 && g.s % 4 == 0));
+  // vector row loads of 4 samples (planar: 16 B fp32 / 8 B fp16 per access) or 4 interleaved RGB pixels: rows and tile
+  // origins must start on a 4-sample boundary
+  const int vec_ok = W % 4 == 0 && g.s % 4 == 0 && (C == 1 ? tdk_aligned(in, 4 * sizeof(T)) : (C == 3 && tdk_aligned(in, 16)));
   TDK_LAUNCH("tdk_wiener(tiles)", (wiener_stream<T, K, OV>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(64 * NWV), 0, st_, in, slabs, W, H, C, c, vec_ok, g,
              sigmas, prm, nplanes, C == 1 ? (size_t)W * H : (size_t)0);
   return TDK_OK;
