@@ -110,6 +110,19 @@ __device__ __forceinline__ void partner2(float& a, float& b, unsigned long long 
                : [a] "+v"(a), [b] "+v"(b), [ta] "=&v"(ta), [tb] "=&v"(tb) : [m] "s"(self));
 }
 
+// Sum over the K lanes of a slot, result in every lane: quad butterflies and row rotations as DPP operands of the adds
+// (v_add_f32_dpp, ~4.5 cycles), one ds_bpermute (~24 cycles, through the LDS pipe) only for the two 16-lane rows of a
+// K = 32 slot -- the plain __shfl_xor butterfly is five of them.
+template <int K> __device__ __forceinline__ float slot_sum(float v) {
+  auto dpp = [](float x, auto CTRL) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(CTRL)::value, 0xF, 0xF, true)); };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{});  // row_ror:8  -> sum of the 16-lane row
+  if constexpr (K == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
 // Transpose the K x K tile each slot holds one row per lane through a wave-private LDS buffer (LDS operations
 // of one wave execute in issue order, so only compiler fences are needed, no barrier).  K = 16: the four
 // slots of the wave go at once (4 x 16 x 17 floats); K = 32: the two slots take turns in one 32 x 36 buffer --
@@ -271,8 +284,8 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
         for (int k = K; k < WIN; k++) tail += w[k];
         sb = act_b ? sa + tail : 0.0f;  // tile b = columns [S, K + S)
         sa = sa + head;                 // tile a = columns [0, K)
-#pragma unroll
-        for (int o = K / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+        sa = slot_sum<K>(sa);
+        sb = slot_sum<K>(sb);
         const float mean_a = sa / (float)(K * K), mean_b = sb / (float)(K * K);
         const float wyb = act_b ? wy : 0.0f;  // tile b absent: its row factor is 0 (one select instead of K)
         const float ca = -mean_a * wy, cb = -mean_b * wyb;
