@@ -107,8 +107,8 @@ int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float
  * extension.cpp:211-212).  One sample per cell of the (height/stride) x (width/stride) grid, n = sh * sw:
  * chroma[n][2] = (r, g) / (r + g + b), intensity[n] = r + g + b, mask[n] = max(2x2 quad) < 1; the
  * skipped last row / column of cells (:69) is written as invalid (the reference leaves it
- * uninitialised).  literal_positions != 0 reads the quad at pos * 2 as the reference does (:71),
- * 0 reads it at pos * stride (the documented intent).  The quantile / mean (:149-161) are the
+ * uninitialised).  literal_positions != 0 reads the quad at pos * 2 as the reference does (:71) -- the binding's
+ * default --, 0 reads it at pos * stride (the documented intent, an opt-in correction).  The quantile / mean (:149-161) are the
  * binding's device ops, as in the reference.  bayer: (H, W) float32. */
 int tdk_wb_collect_samples(const float* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
                            float* intensity, uint8_t* mask, tdk_stream_t stream);

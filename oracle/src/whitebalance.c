@@ -25,8 +25,9 @@ TDK_API void oracle_apply_white_balance(const float* in, float* out, int width, 
  * Two reference slips, handled explicitly:
  *  - the quad is read at pos * 2 although the grid is sized by `stride` (:71), so the reference
  *    only ever looks at the top-left (2/stride)^2 of the frame.  literal_positions != 0
- *    reproduces that; 0 reads cell (i, j) at (i * stride, j * stride) -- the documented intent
- *    ("Pixel sampling stride", white_balance.py:47) and what the product does;
+ *    reproduces that (the default of the numpy front-end and of the product, which returns the
+ *    reference's gains); 0 reads cell (i, j) at (i * stride, j * stride) -- the documented intent
+ *    ("Pixel sampling stride", white_balance.py:47), an opt-in correction in the product;
  *  - skipped cells leave chroma / intensity / mask uninitialised (torch::empty, :107-109), so
  *    the reference's result depends on stale memory.  Here (and in the product) skipped cells
  *    are invalid (mask = 0, values 0).

@@ -182,7 +182,7 @@ def apply_white_balance(bayer: np.ndarray, gains, pattern: int) -> np.ndarray:
   return out
 
 
-def wb_collect_samples(bayer: np.ndarray, pattern: int, stride: int = 8, literal_positions: bool = False):
+def wb_collect_samples(bayer: np.ndarray, pattern: int, stride: int = 8, literal_positions: bool = True):
   """(chroma (n, 2), intensity (n,), mask (n,) bool) over the full (H/stride) x (W/stride) cell grid."""
   b = _f32(bayer)
   h, w = b.shape
@@ -193,7 +193,7 @@ def wb_collect_samples(bayer: np.ndarray, pattern: int, stride: int = 8, literal
   return chroma, inten, mask.astype(bool)
 
 
-def estimate_white_balance(bayer_images, pattern: int, quantile: float = 0.95, stride: int = 8, literal_positions: bool = False) -> np.ndarray:
+def estimate_white_balance(bayer_images, pattern: int, quantile: float = 0.95, stride: int = 8, literal_positions: bool = True) -> np.ndarray:
   """reference csrc/white_balance.cu:129-161 on top of wb_collect_samples: keep valid samples, select those with
   intensity >= quantile(intensity, q) (torch.quantile: linear interpolation), mean chroma (mr, mg) ->
   gains (mr / mg, 1, (1 - mr - mg) / mg); (1, 1, 1) when nothing is valid."""

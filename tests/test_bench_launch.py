@@ -67,3 +67,14 @@ def test_under_an_external_launcher_two_ranks():
     assert [p.returncode for p in procs] == [0, 0], outs
     (line,) = _json_lines(outs[0][0])
     assert line['n_gpus'] == 2 and _json_lines(outs[1][0]) == []
+
+
+def test_gpus8_rehearsal_eight_ranks():
+    """The shape the driver's scaling run has (BASELINE.json configs[3]: 8 ranks of one node), rehearsed on the CPU:
+    free-port choice, 8 children, gloo barrier + max-over-ranks, reaping, ONE relayed line with ranks_ran == 8."""
+    r = _run(['--gpus', '8'], env_extra={'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr
+    (out,) = _json_lines(r.stdout)
+    assert out['n_gpus'] == 8 and out['ranks_ran'] == 8 and len(out['per_rank_MPps']) == 8
+    assert out['scaling'] == 'weak' and out['value'] <= sum(out['per_rank_MPps']) * (1 + 1e-3)
+    assert r.stdout.count('{') >= 1 and len(_json_lines(r.stdout)) == 1  # no rank but 0 prints a line

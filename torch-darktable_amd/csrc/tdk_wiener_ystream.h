@@ -1,0 +1,317 @@
+// tdk_wiener_ystream.h -- the tile kernel of the Wiener denoiser for the default tile geometry K = 32, ov = 4
+// (reference csrc/denoise/denoise.cu:151-242 with DenoiseParams tile_size 32, overlap_factor 4: pipeline/config.py).
+// Included by wiener.hip inside its anonymous namespace (shares Geom, WindowK, wiener_gains, the finish kernels).
+//
+// Same arithmetic per tile as wiener_stream (mean removal, separable Gaussian analysis window, 2-D FFT, gain
+// max(|X|^2 + eps - sigma^2, 0) / (|X|^2 + eps), inverse, synthesis window, overlap-add), re-associated so that the
+// work shared by overlapping tiles is done once (profiles/wiener_ystream_proto.py checks the algebra in numpy):
+//  * a workgroup owns a STRIP of 16 tile columns (8 tile pairs: two adjacent tiles ride one complex transform) and
+//    walks DOWN the image, one tile row = s = 8 new image rows per step;
+//  * forward row FFT: an 8-row block of the strip is transformed ONCE (64 lanes = 8 block rows x 8 tile pairs, one
+//    32-point complex FFT of (a + i b) * wf[x] per lane, in registers) and used by the 4 tile rows that contain it:
+//    the tile mean and the row factor wf[y] of the window are applied in the (row, kx) domain,
+//    Z[y][kx] = wf[y] (R[y][kx] - mean W[kx]),  W = FFT(wf);
+//  * column pipeline: lane = kx, register = row.  A lane keeps the 32 rows of its tile pair's current window in
+//    registers (8 new rows per step from LDS), runs FFT_y -> gains -> IFFT_y in registers, and overlap-adds ACROSS
+//    tile rows still in the (row, kx) domain: 24 carried rows per lane, the 8 oldest rows are final after each step;
+//  * inverse row FFT: the finished 8-row block is transformed once (again 64 lanes = 8 rows x 8 pairs), multiplied by
+//    the synthesis window, overlap-added along x (inside the tile pair in registers, across pairs by DPP row shifts)
+//    and stored to the strip's slab -- the same slab layout as wiener_stream, so the finish kernels are shared.
+// Per tile this is 2 + 1/4 + 1/4 FFT passes instead of 4, and the only transpositions are the two hand-overs
+// between the row and the column stage (8 rows per step each) instead of four 32 x 32 LDS transposes.
+// The three roles rotate over the 4 waves of a workgroup: every wave runs the column pipeline for its two tile
+// pairs; in step i wave i % 4 also runs the forward row stage and wave (i + 2) % 4 the inverse row stage.
+// Samples reach the row stage through an LDS staging block that all 256 threads fill one step ahead (global loads
+// issued at the top of a step, consumed at its end), so no wave waits on HBM.
+#pragma once
+
+namespace ys {
+
+constexpr int K = 32, S = 8, NPC = 8;     // tile size, hop, tile PAIRS per strip
+constexpr int NTC = 2 * NPC;              // tile columns per strip (Geom::G)
+constexpr int SW = NTC * S + K - S;       // samples per strip row: 152
+constexpr int PITCH = 68;                 // floats per LDS row of 32 complex values (+4: conflict-free 16-B row accesses)
+constexpr int BUF = 64 * PITCH;           // one hand-over block: 8 block rows x 8 tile pairs
+constexpr int GRP_PER_ROW = SW / 4;       // 16-B groups per staged row: 38
+constexpr int GRP_PER_WAVE = 8 * GRP_PER_ROW / 4;  // 76
+
+struct YParams {
+  float whr[32], whi[32];  // FFT of the analysis window wf, natural kx order
+};
+
+struct __align__(16) Smem {
+  float fwd[2][BUF];        // row stage -> column stage: R[block row][kx] (complex interleaved)
+  float inv[2][BUF];        // column stage -> row stage: finished rows [block row][kx]
+  float plane[2][8 * SW];   // staged samples of one 8-row block
+  float meta[8][NPC * 2];   // ring over the last 8 blocks: per tile pair, the sums of the block's samples under tile a / tile b
+};
+static_assert(sizeof(Smem) <= 80 * 1024, "two workgroups per CU");
+
+// LDS row of (tile pair c, block row r) = the lane that owns it in the row stages
+__device__ __forceinline__ constexpr int row_of(int c, int r) { return (r & 1) + 2 * c + 16 * (r >> 1); }
+
+template <int CTRL> __device__ __forceinline__ float dpp0(float x) {  // DPP move, 0 where the source lane does not exist
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+// Raw staging registers: the global loads of a step's samples are issued at the top of the step and only converted /
+// written to LDS at its bottom, so nothing waits on them.
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+  float v[4];
+  __device__ __forceinline__ void load4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  __device__ __forceinline__ void load1(int j, const float* p) { v[j] = *p; }
+  __device__ __forceinline__ void zero(int j) { v[j] = 0.0f; }
+  __device__ __forceinline__ float4 get(bool) const { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Raw4<__half> {
+  unsigned v[4];  // vector path: two packed pairs in v[0], v[1]; scalar path: one sample per register
+  __device__ __forceinline__ void load4(const __half* p) { const uint2 t = *reinterpret_cast<const uint2*>(p); v[0] = t.x; v[1] = t.y; }
+  __device__ __forceinline__ void load1(int j, const __half* p) { v[j] = *reinterpret_cast<const unsigned short*>(p); }
+  __device__ __forceinline__ void zero(int j) { v[j] = 0u; }
+  __device__ __forceinline__ float4 get(bool packed) const {
+    auto h = [](unsigned bits) { return __half2float(__ushort_as_half((unsigned short)bits)); };
+    if (packed) return make_float4(h(v[0] & 0xffffu), h(v[0] >> 16), h(v[1] & 0xffffu), h(v[1] >> 16));
+    return make_float4(h(v[0]), h(v[1]), h(v[2]), h(v[3]));
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan0, int vec_ok, Geom g,
+                                                         const float* __restrict__ sigmas, YParams yp, size_t plane_stride) {
+  __shared__ Smem sm;
+  int chan = chan0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ngroups = g.ngx * g.ngy;
+  const int plane = blockIdx.x / ngroups, gin = blockIdx.x - plane * ngroups;
+  const int gy = gin / g.ngx, gx = gin - gy * g.ngx;
+  const float sigma = sigmas[chan + plane];
+  if (C == 3) chan += plane;  // interleaved input: group set p works on channel p of the same image
+  const float sig2 = sigma * sigma;
+  const T* base = img + (size_t)plane * plane_stride;
+  const int t0 = gy * g.TR, t1 = min(t0 + g.TR, g.nty);
+  const int NB = t1 - t0 + 3;                 // 8-row blocks this strip segment reads = blocks its slab holds
+  const int px0 = (g.jmin + gx * NTC) * S;    // image x of strip sample 0
+  // samples beyond the last active tile of the strip are never used (and may lie beyond one reflection of the frame)
+  const int sx_lim = S * min(g.ntx - gx * NTC, NTC) + K - S;
+  float* slab = slabs + (size_t)blockIdx.x * (size_t)(g.RSY * g.RSXP);
+
+  // column-stage coordinates: a 32-lane slot per tile pair, lane = kx (partner bin -kx in lane ^ 1)
+  const int slot = lane >> 5, l = lane & 31, yc = 2 * wave + slot;
+  const int kx = (l == 0) ? 0 : (l == 1) ? K / 2 : (l & 1) ? K - (l >> 1) : (l >> 1);  // == lane_freq(l, K)
+  const bool ya = gx * NTC + 2 * yc < g.ntx, yb = gx * NTC + 2 * yc + 1 < g.ntx;
+  const float whr = yp.whr[kx], whi = yp.whi[kx];
+  const int col_off = 2 * yc * PITCH + 2 * kx;  // this lane's element of block row 0 of its tile pair in a hand-over block
+  // row-stage coordinates: lane = row_of(xc, xr)
+  const int xr = (lane & 1) + 2 * (lane >> 4), xc = (lane >> 1) & 7;
+  const bool xa = gx * NTC + 2 * xc < g.ntx, xb = gx * NTC + 2 * xc + 1 < g.ntx;
+  // staging coordinates: this wave's 76 groups of 4 samples of an 8 x 152 block (lanes < 12 take a second group)
+  const int sg0 = GRP_PER_WAVE * wave + lane, sg1 = sg0 + 64;
+  const bool has1 = lane < GRP_PER_WAVE - 64;
+  const bool vec = vec_ok && C == 1;
+
+  float wr[32], wi[32];      // R[y][kx] of the current window (tile-relative row y)
+  float cr[24], ci[24];      // carried (unfinished) rows of the overlap-add across tile rows, tile-relative
+#pragma unroll
+  for (int k = 0; k < 32; k++) wr[k] = wi[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 24; k++) cr[k] = ci[k] = 0.0f;
+
+  // 4 samples of block q (image rows 8 q - 24 ...), strip columns 4 (grp % 38) ...: issue the loads; true = packed 16-B / 8-B load
+  auto fetch = [&](int grp, int q, Raw4<T>& raw) -> bool {
+    const int brow = grp / GRP_PER_ROW, col = 4 * (grp - brow * GRP_PER_ROW);
+    const int y = reflect_index(8 * q + brow + g.jmin * S, H);
+    const T* rowp = base + (size_t)y * W * C;
+    const int x = px0 + col;
+    if (vec && x >= 0 && x + 4 <= W) {
+      raw.load4(rowp + x);
+      return true;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (col + j < sx_lim) raw.load1(j, rowp + (size_t)reflect_index(x + j, W) * C + chan);
+      else raw.zero(j);
+    }
+    return false;
+  };
+  auto emit = [&](float* dst, const float (&or_)[8], const float (&oi_)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) *reinterpret_cast<float2*>(dst + row_of(0, r) * PITCH) = make_float2(or_[r], oi_[r]);
+  };
+
+  for (int i = 0; i < NB + 6; i++) {
+    // ---- staging, first half: issue the global loads of block i (consumed at the bottom of the step)
+    Raw4<T> st0, st1;
+    bool pk0 = false, pk1 = false;
+    if (i < NB) {
+      pk0 = fetch(sg0, t0 + i, st0);
+      if (has1) pk1 = fetch(sg1, t0 + i, st1);
+    }
+
+    // ---- column stage: block b = i - 2 arrives; tile row t0 + b - 3 is complete from b = 3 on; after the last
+    // block the three carried blocks leave as they are (partial sums for the seam with the next strip segment)
+    const int b = i - 2;
+    if (b >= 0 && b < NB) {
+      // the window moves down one block: rows 8 .. 31 become rows 0 .. 23 (48 register moves: cheaper than what the
+      // compiler makes of a code variant per window phase), the arriving block becomes rows 24 .. 31
+#pragma unroll
+      for (int y = 0; y < 24; y++) { wr[y] = wr[y + 8]; wi[y] = wi[y + 8]; }
+      const float* f = sm.fwd[b & 1] + col_off;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const float2 v = *reinterpret_cast<const float2*>(f + row_of(0, r) * PITCH);
+        wr[24 + r] = v.x;
+        wi[24 + r] = v.y;
+      }
+      if (b >= 3) {
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float2 t = *reinterpret_cast<const float2*>(sm.meta[(b - q) & 7] + 2 * yc);
+          sa += t.x;
+          sb += t.y;
+        }
+        const float mean_a = ya ? sa * (1.0f / (K * K)) : 0.0f, mean_b = yb ? sb * (1.0f / (K * K)) : 0.0f;
+        const float mr = mean_a * whr - mean_b * whi, mi = mean_a * whi + mean_b * whr;  // (mean_a + i mean_b) W[kx]
+        float zr[32], zi[32];
+#pragma unroll
+        for (int y = 0; y < 32; y++) {
+          zr[y] = (wr[y] - mr) * WindowK<32>::w[y];
+          zi[y] = (wi[y] - mi) * WindowK<32>::w[y];
+        }
+        fft_inreg<32, false>(zr, zi);
+        wiener_gains<32>(zr, zi, sig2);
+        fft_inreg<32, true>(zr, zi);
+        // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
+        const float ar = mr * (1.0f / K), ai = mi * (1.0f / K);
+        {
+          float or_[8], oi_[8];
+#pragma unroll
+          for (int y = 0; y < 8; y++) {
+            or_[y] = __builtin_fmaf(WindowK<32>::w[y], __builtin_fmaf(WindowK<32>::w[y], ar, zr[y]), cr[y]);
+            oi_[y] = __builtin_fmaf(WindowK<32>::w[y], __builtin_fmaf(WindowK<32>::w[y], ai, zi[y]), ci[y]);
+          }
+          emit(sm.inv[i & 1] + col_off, or_, oi_);
+        }
+        // the carried rows move up one block while they are updated: row y takes the sum of row y + 8.  In this order every
+        // register is read before it is rewritten; the scheduling barriers keep the order, so the move costs no copies
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          cr[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]), cr[y + 8]);
+          ci[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]), ci[y + 8]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 8; y < 16; y++) {
+          cr[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]), cr[y + 8]);
+          ci[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]), ci[y + 8]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 16; y < 24; y++) {
+          cr[y] = WindowK<32>::w[y + 8] * __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]);
+          ci[y] = WindowK<32>::w[y + 8] * __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]);
+        }
+      }
+    } else if (b >= NB && b < NB + 3) {
+      float or_[8], oi_[8];
+#pragma unroll
+      for (int y = 0; y < 8; y++) { or_[y] = cr[y]; oi_[y] = ci[y]; }
+      emit(sm.inv[i & 1] + col_off, or_, oi_);
+#pragma unroll
+      for (int y = 0; y < 16; y++) { cr[y] = cr[y + 8]; ci[y] = ci[y + 8]; }
+    }
+
+    // ---- forward row stage (wave i % 4): block i - 1 from the staging buffer -> R rows
+    if (wave == (i & 3) && i >= 1 && i - 1 < NB) {
+      const int bb = i - 1;
+      const float* pl = sm.plane[bb & 1] + xr * SW + 2 * S * xc;
+      float w[K + S];
+#pragma unroll
+      for (int k = 0; k < K + S; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(pl + k);
+        w[k] = t.x; w[k + 1] = t.y; w[k + 2] = t.z; w[k + 3] = t.w;
+      }
+      float head = 0.0f, mid = 0.0f, tail = 0.0f;
+#pragma unroll
+      for (int k = 0; k < S; k++) head += w[k];
+#pragma unroll
+      for (int k = S; k < K; k++) mid += w[k];
+#pragma unroll
+      for (int k = K; k < K + S; k++) tail += w[k];
+      // block sums under tile a / tile b: over the 8 block rows = lane bits 0, 4, 5
+      float ba = xa ? head + mid : 0.0f, bb_ = xb ? mid + tail : 0.0f;
+      ba += dpp0<0xB1>(ba); bb_ += dpp0<0xB1>(bb_);  // quad_perm [1,0,3,2]
+      ba += __shfl_xor(ba, 16, 64); bb_ += __shfl_xor(bb_, 16, 64);
+      ba += __shfl_xor(ba, 32, 64); bb_ += __shfl_xor(bb_, 32, 64);
+      if (xr == 0) *reinterpret_cast<float2*>(sm.meta[bb & 7] + 2 * xc) = make_float2(ba, bb_);
+      float re[K], im[K];
+      const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        re[k] = (w[k] * fa) * WindowK<32>::w[k];
+        im[k] = (w[k + S] * fb) * WindowK<32>::w[k];
+      }
+      fft_inreg<32, false>(re, im);
+      float* dst = sm.fwd[bb & 1] + lane * PITCH;
+#pragma unroll
+      for (int k = 0; k < K; k += 2) *reinterpret_cast<float4*>(dst + 2 * k) = make_float4(re[k], im[k], re[k + 1], im[k + 1]);
+    }
+
+    // ---- inverse row stage (wave (i + 2) % 4): the block emitted in step i - 1 (slab block e = i - 6)
+    if (wave == ((i + 2) & 3) && i >= 6) {
+      const int e = i - 6;
+      const float* src = sm.inv[(i - 1) & 1] + lane * PITCH;
+      float re[K], im[K];
+#pragma unroll
+      for (int k = 0; k < K; k += 2) {
+        const float4 t = *reinterpret_cast<const float4*>(src + 2 * k);
+        re[k] = t.x; im[k] = t.y; re[k + 1] = t.z; im[k + 1] = t.w;
+      }
+      fft_inreg<32, true>(re, im);  // re = row of tile a, im = row of tile b (columns S further)
+      float s_[K + S];
+#pragma unroll
+      for (int u = 0; u < K + S; u++) {
+        float v = (u < K) ? re[u] * WindowK<32>::w[u] : 0.0f;
+        if (u >= S) v = (u < K) ? __builtin_fmaf(im[u - S], WindowK<32>::w[u - S], v) : im[u - S] * WindowK<32>::w[u - S];
+        s_[u] = v;
+      }
+      // overlap-add along x across tile pairs: pair c's samples [16, 32) belong to pair c + 1's [0, 16), its [32, 40) to
+      // pair c + 2's [0, 8) -- two and four lanes up in the 16-lane DPP row (lane = (r & 1) + 2 c + 16 (r >> 1))
+      float* srow = slab + (size_t)(8 * e + xr) * g.RSXP;
+      float tl[K - S];
+#pragma unroll
+      for (int k = 0; k < K - S; k++) {                       // the strip's last 24 columns (held by pair 7; pair 6 adds 8 of them)
+        float v = s_[2 * S + k];
+        if (k < S) v += dpp0<0x112>(s_[4 * S + k]);
+        asm volatile("" : "+v"(v));                           // keep the DPP reads out of the lane-masked branch below
+        tl[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 2 * S; k += 4) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          o[j] = s_[k + j] + dpp0<0x112>(s_[2 * S + k + j]);        // row_shr:2
+          if (k + j < S) o[j] += dpp0<0x114>(s_[4 * S + k + j]);    // row_shr:4
+        }
+        *reinterpret_cast<float4*>(srow + 2 * S * xc + k) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      if (xc == NPC - 1) {
+#pragma unroll
+        for (int k = 0; k < K - S; k += 4) *reinterpret_cast<float4*>(srow + NTC * S + k) = make_float4(tl[k], tl[k + 1], tl[k + 2], tl[k + 3]);
+      }
+    }
+
+    // ---- staging, second half: the samples loaded at the top go to LDS for the next step's forward row stage
+    if (i < NB) {
+      float* pl = sm.plane[i & 1];
+      *reinterpret_cast<float4*>(pl + 4 * sg0) = st0.get(pk0);
+      if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = st1.get(pk1);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace ys

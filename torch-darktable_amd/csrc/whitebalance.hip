@@ -8,8 +8,9 @@
 //
 // Two reference slips are handled explicitly:
 //  * the reference reads the quad at pos * 2 although the grid is sized by `stride` (:71), i.e. it
-//    only looks at the top-left (2/stride)^2 of the frame: `literal_positions` reproduces that,
-//    the default (0) reads cell (i, j) at (i * stride, j * stride) -- the documented intent;
+//    only looks at the top-left (2/stride)^2 of the frame: `literal_positions` != 0 reproduces that and is what the
+//    binding passes by default (same gains as the reference); 0 reads cell (i, j) at (i * stride, j * stride), the
+//    documented intent, as an opt-in correction;
 //  * it leaves the skipped last row / column of cells uninitialised (torch::empty, :107-109):
 //    here they are written as invalid (mask 0, values 0), so the result is a function of the input.
 // Arithmetic is + * / max only: bit-exact against oracle/src/whitebalance.c.

@@ -180,6 +180,43 @@ template <int K, bool INV> __device__ __forceinline__ void transpose_lds(float (
   }
 }
 
+// Separate the spectra of the two real tiles packed as z = a + i b, apply the gains (denoise.cu:181-185), recombine.  With
+// 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])):  Z'[k] = ga A + i gb B and, because A and B
+// are spectra of real tiles, Z'[-k] = ga conj(A) + i gb conj(B) -- the same gains and products.  Z[-k]
+// lives in the partner lane (column -kx) at register -ky and the partner needs exactly the mirrored
+// pair, so every lane evaluates only ky = k (k = 0..K/2) plus the by-product for the partner's register
+// K - k, and the two lanes swap by-products: half the gain arithmetic of evaluating every bin.  The 1/2
+// of A, B and the 1/K^2 of the two unscaled inverse passes are powers of two folded into the gain.
+// gain = max(1 - sigma^2 / p, 0) with p = |A|^2 + eps, evaluated on p4 = |2A|^2 + 4 eps as
+// max(GS - (4 sigma^2 GS) / p4, 0): two FMAs for p4, then rcp + FMA + max.
+// Input: lane = kx (frequency -> lane assignment lane_freq, Hermitian partner in lane ^ 1), register = ky, after the two
+// unscaled forward passes; output: ready for the two unscaled inverse passes.
+template <int K> __device__ __forceinline__ void wiener_gains(float (&re)[K], float (&im)[K], float sig2) {
+  // the two self-conjugate lanes (kx = 0 and K/2) of every slot
+  constexpr unsigned long long SELF = (K == 32) ? 0x0000000300000003ull : 0x0003000300030003ull;
+  constexpr float GSCALE = 0.5f / (float)(K * K);
+  float sgs = -4.0f * sig2 * GSCALE;
+  asm volatile("" : "+v"(sgs));  // keep it in a VGPR: a VALU instruction with an SGPR operand issues at half rate
+#pragma unroll
+  for (int k = 0; k <= K / 2; k++) {
+    const int k2 = (K - k) & (K - 1);
+    const float zr = re[k], zi = im[k];
+    float pr = re[k2], pi = im[k2];
+    partner2(pr, pi, SELF);  // Z[-k]
+    const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
+    const float pa4 = __builtin_fmaf(a2i, a2i, __builtin_fmaf(a2r, a2r, 4e-15f)), pb4 = __builtin_fmaf(b2i, b2i, __builtin_fmaf(b2r, b2r, 4e-15f));
+    const float ga = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
+    const float gb = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
+    const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
+    re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
+    if (k2 != k) {
+      float br_ = gar + gbi, bi_ = gbr - gai;             // my Z'[K-k] is the partner's by-product
+      partner2(br_, bi_, SELF);
+      re[k2] = br_; im[k2] = bi_;
+    }
+  }
+}
+
 // One workgroup = one group: TR = 4 * (64 / K) consecutive tile rows x G tile columns of one plane.
 // NBUF = 2 double-buffers the hand-off block (one barrier per step); 1 when that would not leave room
 // for two workgroups per CU (K = 32, ov = 2: 32 KB per buffer).
@@ -215,8 +252,6 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
   if (C == 3) chan += plane;  // interleaved input: group set p works on channel p of the same image
   const float sig2 = sigma * sigma;
   const float wy = prm.wf[row], iy = prm.wi[row];
-  // the two self-conjugate lanes (kx = 0 and K/2) of every slot
-  constexpr unsigned long long SELF = (K == 32) ? 0x0000000300000003ull : 0x0003000300030003ull;
   float* slab = slabs + (size_t)blockIdx.x * (size_t)(g.RSY * g.RSXP);
   const int steps = g.G >> 1;
 
@@ -307,38 +342,7 @@ __global__ __launch_bounds__(64 * NWV, TDK_WIENER_WAVES_PER_SIMD) void wiener_st
       transpose_lds<K, false>(im, tbuf, slot, row, fcol);
       fft_inreg<K, false>(re, im);  // lane = kx, register = ky
 
-      // ---- separate the two spectra, apply the gains (denoise.cu:181-185), recombine.  With
-      // 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])):  Z'[k] = ga A + i gb B and, because A and B
-      // are spectra of real tiles, Z'[-k] = ga conj(A) + i gb conj(B) -- the same gains and products.  Z[-k]
-      // lives in the partner lane (column -kx) at register -ky and the partner needs exactly the mirrored
-      // pair, so every lane evaluates only ky = k (k = 0..K/2) plus the by-product for the partner's register
-      // K - k, and the two lanes swap by-products: half the gain arithmetic of evaluating every bin.  The 1/2
-      // of A, B and the 1/K^2 of the two unscaled inverse passes are powers of two folded into the gain.
-      // gain = max(1 - sigma^2 / p, 0) with p = |A|^2 + eps, evaluated on p4 = |2A|^2 + 4 eps as
-      // max(GS - (4 sigma^2 GS) / p4, 0): two FMAs for p4, then rcp + FMA + max.
-      {
-        constexpr float GSCALE = 0.5f / (float)(K * K);
-        float sgs = -4.0f * sig2 * GSCALE;
-        asm volatile("" : "+v"(sgs));  // keep it in a VGPR: a VALU instruction with an SGPR operand issues at half rate
-#pragma unroll
-        for (int k = 0; k <= K / 2; k++) {
-          const int k2 = (K - k) & (K - 1);
-          const float zr = re[k], zi = im[k];
-          float pr = re[k2], pi = im[k2];
-          partner2(pr, pi, SELF);  // Z[-k]
-          const float a2r = zr + pr, a2i = zi - pi, b2r = zi + pi, b2i = pr - zr;
-          const float pa4 = __builtin_fmaf(a2i, a2i, __builtin_fmaf(a2r, a2r, 4e-15f)), pb4 = __builtin_fmaf(b2i, b2i, __builtin_fmaf(b2r, b2r, 4e-15f));
-          const float ga = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
-          const float gb = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
-          const float gar = ga * a2r, gai = ga * a2i, gbr = gb * b2r, gbi = gb * b2i;
-          re[k] = gar - gbi; im[k] = gai + gbr;                 // Z'[k]
-          if (k2 != k) {
-            float br_ = gar + gbi, bi_ = gbr - gai;             // my Z'[K-k] is the partner's by-product
-            partner2(br_, bi_, SELF);
-            re[k2] = br_; im[k2] = bi_;
-          }
-        }
-      }
+      wiener_gains<K>(re, im, sig2);  // Hermitian split of the two tiles, gains, recombination
 
       // ---- inverse: along y, transpose back (lane = y again, register = kx in natural order), along x
       fft_inreg<K, true>(re, im);
@@ -562,6 +566,8 @@ __global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ 
   }
 }
 
+#include "tdk_wiener_ystream.h"
+
 void make_window(int K, double weight, float* w) {
   const double half = K / 2.0, scale = weight * half * half;
   double v[32], nrm = 0.0;
@@ -600,16 +606,111 @@ Geom geometry(int W, int H, int K, int ov, int G) {
 
 size_t slab_floats(const Geom& g) { return (size_t)g.ngx * g.ngy * g.RSXP * g.RSY; }
 
+// Geometry of the y-streaming kernel (tdk_wiener_ystream.h; K = 32, ov = 4): a group = a strip of 16 tile columns x TR
+// tile rows, same slab layout.
+constexpr int YS_TR_MIN = 8;
+Geom geometry_ys(int W, int H, int TR) {
+  Geom g = {};
+  g.s = ys::S;
+  g.K = ys::K;
+  g.jmin = -(ys::K / ys::S - 1);
+  g.ntx = (W - 1) / g.s - g.jmin + 1;
+  g.nty = (H - 1) / g.s - g.jmin + 1;
+  g.TR = TR;
+  g.G = ys::NTC;
+  g.ngx = tdk_div_up(g.ntx, g.G);
+  g.ngy = tdk_div_up(g.nty, g.TR);
+  g.BSX = g.G * g.s;
+  g.BSY = g.TR * g.s;
+  g.RSX = g.BSX + g.K - g.s;
+  g.RSXP = (g.RSX + 3) & ~3;
+  g.RSY = g.BSY + g.K - g.s;
+  g.magic_x = (unsigned)((0x100000000ull + g.BSX - 1) / g.BSX);
+  g.magic_y = (unsigned)((0x100000000ull + g.BSY - 1) / g.BSY);
+  return g;
+}
+static_assert(ys::SW % 4 == 0, "slab row pitch = strip width");
+
+inline bool use_ystream(int K, int ov) {
+#ifdef TDK_EXPERIMENTS
+  if (const char* e = getenv("TDK_WIENER_YSTREAM")) return atoi(e) != 0 && K == 32 && ov == 4;
+#endif
+  return K == 32 && ov == 4;
+}
+
+// Slab floats the workspace holds per plane: the worst case of whichever tile kernel serves (K, ov).
+size_t slab_cap_floats(int W, int H, int K, int ov) {
+  size_t cap = slab_floats(geometry(W, H, K, ov, 0));
+  if (K == 32 && ov == 4) {
+    const size_t c2 = slab_floats(geometry_ys(W, H, YS_TR_MIN));
+    if (c2 > cap) cap = c2;
+  }
+  return cap;
+}
+
+// Tile rows per strip segment: the launch is one workgroup per (strip, segment) with 2 resident per CU; a segment of TR
+// tile rows costs TR full steps plus about 4 steps' worth of pipeline fill and drain.  Fewest rounds x steps wins.
+int pick_segment_rows(int W, int H, int nplanes) {
+  const Geom g0 = geometry_ys(W, H, YS_TR_MIN);
+  const size_t cap = slab_cap_floats(W, H, 32, 4);
+  const long slots = (long)tdk_device_cus() * 2;
+  int best = YS_TR_MIN;
+  double best_cost = 1e30;
+#ifdef TDK_EXPERIMENTS
+  if (const char* e = getenv("TDK_WIENER_TR")) {
+    const int tr = atoi(e);
+    if (tr >= YS_TR_MIN && slab_floats(geometry_ys(W, H, tr)) <= cap) return tr;
+  }
+#endif
+  for (int tr = YS_TR_MIN; tr <= (g0.nty > YS_TR_MIN ? g0.nty : YS_TR_MIN); tr++) {
+    const Geom g = geometry_ys(W, H, tr);
+    if (slab_floats(g) > cap) continue;
+    const long groups = (long)g.ngx * g.ngy * nplanes;
+    const long rounds = (groups + slots - 1) / slots;
+    const double cost = (double)rounds * (tr + 4.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = tr; }
+  }
+  return best;
+}
+
+ys::YParams make_yparams() {
+  float wf[32];
+  make_window(32, 0.3, wf);
+  ys::YParams yp = {};
+  for (int kx = 0; kx < 32; kx++) {
+    double re = 0.0, im = 0.0;
+    for (int k = 0; k < 32; k++) {
+      const double a = -2.0 * M_PI * (double)((k * kx) & 31) / 32.0;
+      re += (double)wf[k] * cos(a);
+      im += (double)wf[k] * sin(a);
+    }
+    yp.whr[kx] = (float)re;
+    yp.whi[kx] = (float)im;
+  }
+  return yp;
+}
+
+template <typename T>
+int launch_tiles_ys(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, hipStream_t st_, int nplanes) {
+  const int vec_ok = W % 4 == 0 && (C == 1 ? tdk_aligned(in, 4 * sizeof(T)) : (C == 3 && tdk_aligned(in, 16)));
+  static const ys::YParams yp = make_yparams();
+  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(256), 0, st_, in, slabs, W, H, C, c, vec_ok, g, sigmas, yp,
+             C == 1 ? (size_t)W * H : (size_t)0);
+  return TDK_OK;
+}
+
 // Group width: the launch is one workgroup per group with `per_cu` workgroups resident per CU, so the run
 // time is ceil(groups / slots) rounds of one group's duration -- pick the width whose last round is
 // fullest (ties: wider groups = fewer seam columns), never using more slab than the workspace (G_MIN) holds.
 int pick_group_width(int W, int H, int K, int ov, int nplanes, int per_cu) {
-  if (const char* e = getenv("TDK_WIENER_G")) {  // experiments only
-    const int G = atoi(e);
-    if (G >= G_MIN && G <= G_MAX && (G & 1) == 0) return G;
-  }
   const int slots = tdk_device_cus() * per_cu;
   const size_t cap = slab_floats(geometry(W, H, K, ov, 0));
+#ifdef TDK_EXPERIMENTS
+  if (const char* e = getenv("TDK_WIENER_G")) {
+    const int G = atoi(e);
+    if (G >= G_MIN && G <= G_MAX && (G & 1) == 0 && slab_floats(geometry(W, H, K, ov, G)) <= cap) return G;
+  }
+#endif
   int best = G_MIN;
   double best_eff = -1.0;
   for (int G = G_MIN; G <= G_MAX; G += 2) {
@@ -675,14 +776,16 @@ inline unsigned stream_blocks(int64_t npix) {
 
 template <typename T, int K>
 int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
-  const Geom g = geometry(W, H, K, ov, pick_group_width(W, H, K, ov, C == 3 ? 3 : 1, tiles_per_cu(K, ov)));
+  const bool ysk = use_ystream(K, ov);
+  const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, C == 3 ? 3 : 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, C == 3 ? 3 : 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   if (C == 3) {
     // one tile launch over 3 x groups (group set p = channel p, read straight from the interleaved image) -> one
     // finish that writes whole RGB pixels
     const bool vec = (W % 4) == 0 && tdk_aligned(in, 16) && tdk_aligned(out, 16);
-    const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, 3, 0, ov, sigmas, g, prm, st_, 3);
+    const int rc = ysk ? launch_tiles_ys<T>(reinterpret_cast<const T*>(in), slabs, W, H, 3, 0, sigmas, g, st_, 3)
+                       : launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, 3, 0, ov, sigmas, g, prm, st_, 3);
     if (rc != TDK_OK) return rc;
     const dim3 fgrid((unsigned)tdk_div_up(vec ? W / 4 : W, 256), (unsigned)(H < 32768 ? H : 32768));
     if (vec) TDK_LAUNCH("tdk_wiener(finish)", (wiener_finish3<T, 4>), fgrid, dim3(256), 0, st_, slabs, reinterpret_cast<T*>(out), W, H, g, prm);
@@ -690,7 +793,8 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
     return TDK_OK;
   }
   for (int c = 0; c < C; c++) {
-    const int rc = launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
+    const int rc = ysk ? launch_tiles_ys<T>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, sigmas, g, st_, 1)
+                       : launch_tiles<T, K>(reinterpret_cast<const T*>(in), slabs, W, H, C, c, ov, sigmas, g, prm, st_);
     if (rc != TDK_OK) return rc;
     TDK_LAUNCH("tdk_wiener(finish)", wiener_finish<T>, dim3((unsigned)tdk_div_up(W, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
                reinterpret_cast<T*>(out), W, H, C, c, g, prm);
@@ -702,13 +806,14 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
 template <typename T, int K>
 int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_,
                          float* lum_out = nullptr, int lum_log = 0, float lum_eps = 1e-6f) {
-  const Geom g = geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
+  const bool ysk = use_ystream(K, ov);
+  const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
-  float* plane = slabs + tdk_align_up(slab_floats(geometry(W, H, K, ov, 0)), 64);
+  float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
   int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
   if (rc != TDK_OK) return rc;
-  rc = launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
+  rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
   if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && (!lum_out || tdk_aligned(lum_out, 16)))
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3((unsigned)tdk_div_up(W / 4, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,
@@ -723,7 +828,7 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 
 TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
-  const size_t slabs = slab_floats(geometry(width, height, tile_size, overlap_factor, 0));
+  const size_t slabs = slab_cap_floats(width, height, tile_size, overlap_factor);
   return tdk_align_up((size_t)(channels == 3 ? 3 : 1) * slabs * sizeof(float), 256);  // one slab set per channel
 }
 
@@ -743,7 +848,7 @@ TDK_EXPORT int tdk_wiener(const void* in, void* out, void* workspace, int width,
 
 TDK_EXPORT size_t tdk_wiener_log_luminance_workspace_bytes(int width, int height, int tile_size, int overlap_factor) {
   if (tdk_wiener_workspace_bytes(width, height, 1, tile_size, overlap_factor) == 0) return 0;
-  const size_t slabs = slab_floats(geometry(width, height, tile_size, overlap_factor, 0));
+  const size_t slabs = slab_cap_floats(width, height, tile_size, overlap_factor);
   return tdk_align_up((tdk_align_up(slabs, 64) + (size_t)width * height) * sizeof(float), 256);
 }
 

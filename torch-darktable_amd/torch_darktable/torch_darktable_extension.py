@@ -294,15 +294,17 @@ def apply_white_balance(bayer_image: torch.Tensor, gains: torch.Tensor, pattern)
 
 
 def estimate_white_balance(bayer_images: Sequence[torch.Tensor], pattern, quantile: float = 0.95, stride: int = 8,
-                           literal_positions: bool = False) -> torch.Tensor:
+                           literal_positions: bool = True) -> torch.Tensor:
   """reference csrc/white_balance.cu:57-161.  Sample collection is one HIP kernel per image
   (tdk_wb_collect_samples); masking, the intensity quantile and the chroma mean are torch ops on
   the device, as in the reference (white_balance.cu:119-161) -- no host synchronisation except the
   shape-dependent boolean indexing the reference has too.
 
-  Two reference slips are NOT reproduced by default: it samples 2x2 cells
-  at `pos * 2` although the grid is sized by `stride` (`literal_positions=True` reproduces that
-  read pattern), and it leaves the skipped last row / column of cells uninitialised; here every
+  Default = the reference's read pattern: the quad of grid cell `pos` is read at `pos * 2` although the grid is sized by
+  `stride` (white_balance.cu:71), so the estimate only looks at the top-left (2 / stride)^2 of the frame -- deterministic
+  reference behaviour, reproduced so that a drop-in caller gets the reference's gains.  `literal_positions=False` is the
+  opt-in correction (quads at `pos * stride`, the whole frame).  The one deliberate deviation in both modes: the reference
+  leaves the skipped last row / column of cells uninitialised (:69, 107-109: its result depends on stale memory); here every
   entry is defined (skipped cells are invalid)."""
   if len(bayer_images) == 0:
     raise RuntimeError('No images provided')
@@ -520,6 +522,7 @@ class MetricsAccumulator:
 
   def add(self, image: torch.Tensor) -> None:
     _check_rgb(image, allow_half=True)
+    _require(image.device == self.acc.device, f'image is on {image.device}, the accumulator on {self.acc.device}')
     x = image.contiguous()
     with torch.cuda.device(x.device):
       try:
@@ -758,6 +761,11 @@ class JpegSubsampling(enum.IntEnum):
   CSS_444 = 0
   CSS_422 = 1
   CSS_GRAY = 2
+
+
+# pybind's .export_values() (extension.cpp:231-245): the members are also module attributes
+globals().update(JpegInputFormat.__members__)
+globals().update(JpegSubsampling.__members__)
 
 
 class Jpeg:
