@@ -194,6 +194,9 @@ int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r,
 size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
 int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
                   float detail, int dtype, tdk_stream_t stream);
+/* Test hook, process-wide: 0 = automatic (sigma_s <= 4: one LDS tile kernel; otherwise splat / blur / blur / slice as in
+ * bilateral.cu:358-385), 1 = always the four-kernel path.  Both give the same bits; tests compare them. */
+int tdk_bilateral_select_path(int path);
 
 /* Bilateral.process_rgb / process_log_rgb as ONE call (reference torch_darktable/local_contrast.py:109-125:
  * compute_[log_]luminance -> Bilateral.process -> modify_[log_]luminance). */

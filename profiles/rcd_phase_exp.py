@@ -1,9 +1,9 @@
 """Experiment: where the RCD tile kernel spends its time.  Variant libraries built with -DTDK_RCD_STOP=k return
 after phase k (results are wrong, only the duration matters):
-    for k in 0..5: TDK_EXTRA_FLAGS=-DTDK_RCD_STOP=$k python torch-darktable_amd/build.py --force; cp .../libtdk_hip.so variants/rcd_stop$k.so
+    for k in 0..5: TDK_EXTRA_FLAGS="-DTDK_EXPERIMENTS -DTDK_RCD_STOP=$k" python torch-darktable_amd/build.py --force; cp .../libtdk_hip.so variants/rcd_stop$k.so
     python profiles/rcd_phase_exp.py variants/rcd_stop*.so variants/rcd_full.so
 Each library is timed in its own process (12 MP, fp16 in / fp16 out and fp32 / fp32).
-A library built with -DTDK_RCD_TIMING=1 also reports clock64() deltas per phase of one workgroup (entries: 0 = end
+A library built with -DTDK_EXPERIMENTS -DTDK_RCD_TIMING=1 also reports clock64() deltas per phase of one workgroup (entries: 0 = end
 barrier + load phase + prefetch issue, 1..6 = phases P1..P6), in cycles per tile."""
 import ctypes as C
 import json

@@ -366,7 +366,7 @@ def test_bilateral(td, oracle, dev, scene, sig):
 
 @pytest.mark.parametrize('sig', [(2.0, 0.2), (1.0, 0.25), (4.0, 0.1), (2.5, 0.07), (3.0, 0.02)])
 @pytest.mark.parametrize('size', [(256, 192), (324, 130), (67, 45)])
-def test_bilateral_tile_kernel(td, oracle, dev, scene, sig, size, monkeypatch):
+def test_bilateral_tile_kernel(td, oracle, dev, scene, sig, size):
     """Small sigma_s takes the fused LDS tile kernel (grid never in HBM); it must equal the oracle
     AND the four-kernel path bit for bit, for planes (fp32 / fp16) and for the RGB epilogues."""
     w, h = size
@@ -380,10 +380,14 @@ def test_bilateral_tile_kernel(td, oracle, dev, scene, sig, size, monkeypatch):
     assert np.array_equal(got16, oracle.bilateral(lum16.astype(np.float32), sig[0], sig[1], 0.4).astype(np.float16))
     rgb_fused = npy(ws.process_rgb(gpu(img, dev), 0.4))
     log_fused = npy(ws.process_log_rgb(gpu(img, dev), 0.4))
-    monkeypatch.setenv('TDK_BILATERAL_NO_FUSE', '1')
-    assert np.array_equal(npy(ws.process(gpu(lum, dev), 0.4)), got)
-    assert np.array_equal(npy(ws.process_rgb(gpu(img, dev), 0.4)), rgb_fused)
-    assert np.array_equal(npy(ws.process_log_rgb(gpu(img, dev), 0.4)), log_fused)
+    from torch_darktable._native import lib
+    assert lib.tdk_bilateral_select_path(1) == 0  # the general four-kernel path, same parameters
+    try:
+        assert np.array_equal(npy(ws.process(gpu(lum, dev), 0.4)), got)
+        assert np.array_equal(npy(ws.process_rgb(gpu(img, dev), 0.4)), rgb_fused)
+        assert np.array_equal(npy(ws.process_log_rgb(gpu(img, dev), 0.4)), log_fused)
+    finally:
+        assert lib.tdk_bilateral_select_path(0) == 0
 
 
 @pytest.mark.parametrize('K,ov', [(32, 4), (32, 2), (16, 4), (16, 8), (32, 8), (16, 2)])

@@ -24,6 +24,8 @@
 //  formulas (x + 0 == x); and the gather sums in raster order, so the whole op is bit-identical to the oracle.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "tdk_color.h"
 
 #ifdef TDK_BIL_TIMING
@@ -552,9 +554,12 @@ static int tile_maxc(float sigma_s) {
   return ((2.0f * sigma_s + 5.0f <= 8.0f) || (sigma_s == floorf(sigma_s) && 2.0f * sigma_s + 3.0f <= 8.0f)) ? 8 : 14;
 }
 
+// test hook (tdk_bilateral_select_path): take the general four-kernel path even where the tile kernel applies
+static std::atomic<int> g_force_general_path{0};
+
 static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, TileLds* L, size_t* lds_bytes) {
   const int maxc = tile_maxc(sigma_s);  // sigma_s <= 4: 2 * 4 + 5 <= 14
-  if (getenv("TDK_BILATERAL_NO_FUSE")) return false;
+  if (g_force_general_path.load(std::memory_order_relaxed)) return false;
   if (!(sigma_s >= 1.0f && sigma_s <= 4.0f)) return false;
   // no pixel may be clamped onto the last column / row (those columns collect far-away pixels)
   if ((float)(width - 1) / sigma_s > (float)(d.sx - 1) || (float)(height - 1) / sigma_s > (float)(d.sy - 1)) return false;
@@ -673,6 +678,12 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
 }
 
 }  // namespace
+
+TDK_EXPORT int tdk_bilateral_select_path(int path) {
+  TDK_REQUIRE(path == 0 || path == 1, "tdk_bilateral_select_path: path must be 0 (automatic) or 1 (general four-kernel path)");
+  g_force_general_path.store(path, std::memory_order_relaxed);
+  return TDK_OK;
+}
 
 TDK_EXPORT int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]) {
   TDK_REQUIRE(width > 0 && height > 0 && sigma_r > 0.0f && size_xyz, "tdk_bilateral_grid_size: invalid arguments");

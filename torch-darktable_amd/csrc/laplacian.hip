@@ -504,12 +504,7 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     auto fits = [&](int lv) { return (size_t)NP * L.lw(lv + 1) * L.lh(lv + 1) * sizeof(__half) <= 150 * 1024; };  // its coarser level in LDS, 7 pyramids
     while (bottom - 1 >= 1 && small(bottom - 1) && fits(bottom - 1)) bottom--;
     const size_t lds = (size_t)NP * L.lw(bottom + 1) * L.lh(bottom + 1) * sizeof(__half);  // the largest coarser level staged
-    static bool attr_set = false;
-    if (!attr_set) {
-      TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                   "tdk_laplacian(hipFuncSetAttribute)");
-      attr_set = true;
-    }
+    TDK_MAX_LDS_ONCE(deep_assemble_kernel, "tdk_laplacian(hipFuncSetAttribute)");
     TDK_LAUNCH("tdk_laplacian(deep assemble)", deep_assemble_kernel, dim3(1), dim3(1024), lds, s, L, need, a, bottom);
     a = bottom - 1;
   }

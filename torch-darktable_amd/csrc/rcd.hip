@@ -655,18 +655,18 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   T* out = reinterpret_cast<T*>(rgb);
   const int wide_ok = tdk_aligned(bayer, 2 * sizeof(TI));  // sample pairs load as one 8-B / 4-B access (w is even)
   constexpr size_t lds_bytes = (size_t)5 * PLANE * sizeof(float) + (NT / 64) * sizeof(uint32_t);  // planes + the per-wave range verdicts
-  static bool attr_set = false;  // a property of the function (per template instance), set once per process
-  if (!attr_set) {
-    TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcd_interior<TI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
-                 "tdk_rcd(hipFuncSetAttribute)");
-    attr_set = true;
+  {
+    const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rcd_interior<TI, T>), (int)lds_bytes, "tdk_rcd(hipFuncSetAttribute)");
+    if (rc != TDK_OK) return rc;
   }
   const int rband = h < 14 ? h : 14, cband = w < 14 ? w : 14;
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
     int grid = tdk_device_cus();  // one resident workgroup per CU
-    if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + tiles_x * tiles_y;  // experiments: 0 = one item per workgroup
+#ifdef TDK_EXPERIMENTS
+    if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + tiles_x * tiles_y;  // 0 = one item per workgroup
+#endif
     if (grid > nborder + tiles_x * tiles_y) grid = nborder + tiles_x * tiles_y;
     TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y);
   } else {

@@ -4,7 +4,9 @@
 
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "tdk_common.h"
@@ -26,6 +28,18 @@ void tdk_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
+}
+
+int tdk_raise_lds_limit(const void* func, int bytes, const char* what) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;  // (device, kernel function)
+  int dev = 0;
+  TDK_HIP_CALL(hipGetDevice(&dev), what);
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, func})) return TDK_OK;
+  TDK_HIP_CALL(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+  done.insert({dev, func});
+  return TDK_OK;
 }
 
 TDK_EXPORT int tdk_abi_version(void) { return TDK_ABI_VERSION; }

@@ -15,6 +15,14 @@
 
 #define TDK_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Experiment scaffolding (per-phase clocks, truncated kernels, getenv launch knobs: profiles/*_exp.py) is compiled only
+// into -DTDK_EXPERIMENTS builds; the default library has none of it, so a debug path can never be the one that is timed.
+#ifndef TDK_EXPERIMENTS
+#undef TDK_RCD_TIMING
+#undef TDK_RCD_STOP
+#undef TDK_BIL_TIMING
+#endif
+
 // ---------------------------------------------------------------- host side: status + launch checks
 void tdk_set_error(const char* fmt, ...);
 int tdk_device_cus();  // compute units of the current device (cached)
@@ -60,15 +68,13 @@ extern bool g_tdk_profile_on;
     TDK_CHECK_LAUNCH(name);                                                           \
   } while (0)
 
-// Raise a kernel's dynamic-LDS limit to the CU's 160 KB once per process and template instance (a property of the
-// function, not of the launch): keeps hipFuncSetAttribute off the per-call path.
-#define TDK_MAX_LDS_ONCE(kernel, what)                                                                                                     \
-  do {                                                                                                                                      \
-    static bool tdk_attr_set_ = false;                                                                                                      \
-    if (!tdk_attr_set_) {                                                                                                                   \
-      TDK_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), what); \
-      tdk_attr_set_ = true;                                                                                                                 \
-    }                                                                                                                                       \
+// Raise a kernel's dynamic-LDS limit (a property of the function on a device): done once per (device, function), under a
+// lock (runtime.hip), so hipFuncSetAttribute stays off the per-call path and a second GPU or thread is still served.
+int tdk_raise_lds_limit(const void* func, int bytes, const char* what);
+#define TDK_MAX_LDS_ONCE(kernel, what)                                                                   \
+  do {                                                                                                    \
+    const int tdk_rc_ = tdk_raise_lds_limit(reinterpret_cast<const void*>(&kernel), 160 * 1024, what);    \
+    if (tdk_rc_ != TDK_OK) return tdk_rc_;                                                                \
   } while (0)
 
 static inline int tdk_div_up(int a, int b) { return (a + b - 1) / b; }

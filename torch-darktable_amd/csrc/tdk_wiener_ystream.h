@@ -27,6 +27,12 @@
 
 namespace ys {
 
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_ABLATE)
+#define YS_ABLATE(n) (TDK_YS_ABLATE == (n))  // timing-only builds (wrong results): profiles/wiener_ablate_exp.py
+#else
+#define YS_ABLATE(n) false
+#endif
+
 constexpr int K = 32, S = 8, NPC = 8;     // tile size, hop, tile PAIRS per strip
 constexpr int NTC = 2 * NPC;              // tile columns per strip (Geom::G)
 constexpr int SW = NTC * S + K - S;       // samples per strip row: 152
@@ -76,9 +82,36 @@ template <> struct Raw4<__half> {
   }
 };
 
-template <typename T>
+// Four interleaved RGB pixels as loaded (fused log-luminance input): converted at the bottom of the step.
+template <typename T> struct RawRgb4;
+template <> struct RawRgb4<float> {
+  float4 a, b, c;
+  __device__ __forceinline__ void load(const float* p) { const float4* q = reinterpret_cast<const float4*>(p); a = q[0]; b = q[1]; c = q[2]; }
+  __device__ __forceinline__ void get(float (&v)[12]) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+  }
+};
+template <> struct RawRgb4<__half> {
+  uint2 a, b, c;
+  __device__ __forceinline__ void load(const __half* p) { const uint2* q = reinterpret_cast<const uint2*>(p); a = q[0]; b = q[1]; c = q[2]; }
+  __device__ __forceinline__ void get(float (&v)[12]) const {
+    const unsigned w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      v[2 * k] = __half2float(__ushort_as_half((unsigned short)(w[k] & 0xffffu)));
+      v[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(w[k] >> 16)));
+    }
+  }
+};
+
+// LUM = false: the samples are one plane (C = 1) or one channel of an interleaved image (C = 3).
+// LUM = true: the image is interleaved RGB and the samples are its log-lightness log(max(eps, Lab L)) -- exactly the
+// values compute_log_luminance (color.hip, lum_extract_vec4) would have written to a plane first (reference
+// denoise.py:54-56).  The conversion is done by the two waves of a step that run no row stage, in the time they
+// would otherwise wait at the barrier for the two that do.
+template <typename T, bool LUM>
 __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan0, int vec_ok, Geom g,
-                                                         const float* __restrict__ sigmas, YParams yp, size_t plane_stride) {
+                                                         const float* __restrict__ sigmas, YParams yp, size_t plane_stride, float lum_eps) {
   __shared__ Smem sm;
   int chan = chan0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -142,10 +175,28 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
   for (int i = 0; i < NB + 6; i++) {
     // ---- staging, first half: issue the global loads of block i (consumed at the bottom of the step)
     Raw4<T> st0, st1;
-    bool pk0 = false, pk1 = false;
-    if (i < NB) {
-      pk0 = fetch(sg0, t0 + i, st0);
-      if (has1) pk1 = fetch(sg1, t0 + i, st1);
+    RawRgb4<T> px[3];
+    bool pk0 = false, pk1 = false, pkx[3] = {false, false, false};
+    const int lum_half = wave == ((i + 1) & 3) ? 0 : (wave == ((i + 3) & 3) ? 1 : -1);  // LUM: this wave converts block rows 4 h .. 4 h + 3
+    if constexpr (!LUM) {
+      if (i < NB) {
+        pk0 = fetch(sg0, t0 + i, st0);
+        if (has1) pk1 = fetch(sg1, t0 + i, st1);
+      }
+    } else {
+      if (i < NB && lum_half >= 0) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int grp = lane + 64 * u;  // of the 4 x 38 groups of this half block
+          if (grp < 4 * GRP_PER_ROW) {
+            const int brow = 4 * lum_half + grp / GRP_PER_ROW, x = px0 + 4 * (grp % GRP_PER_ROW);
+            if (vec_ok && x >= 0 && x + 4 <= W) {
+              px[u].load(base + ((size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W + x) * 3);
+              pkx[u] = true;
+            }
+          }
+        }
+      }
     }
 
     // ---- column stage: block b = i - 2 arrives; tile row t0 + b - 3 is complete from b = 3 on; after the last
@@ -163,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
         wr[24 + r] = v.x;
         wi[24 + r] = v.y;
       }
-      if (b >= 3) {
+      if (b >= 3 && !YS_ABLATE(2)) {
         float sa = 0.0f, sb = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -179,9 +230,9 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
           zr[y] = (wr[y] - mr) * WindowK<32>::w[y];
           zi[y] = (wi[y] - mi) * WindowK<32>::w[y];
         }
-        fft_inreg<32, false>(zr, zi);
-        wiener_gains<32>(zr, zi, sig2);
-        fft_inreg<32, true>(zr, zi);
+        if (!YS_ABLATE(5)) fft_inreg<32, false>(zr, zi);
+        if (!YS_ABLATE(4) && !YS_ABLATE(5)) wiener_gains<32>(zr, zi, sig2);
+        if (!YS_ABLATE(5)) fft_inreg<32, true>(zr, zi);
         // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
         const float ar = mr * (1.0f / K), ai = mi * (1.0f / K);
         {
@@ -224,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
     }
 
     // ---- forward row stage (wave i % 4): block i - 1 from the staging buffer -> R rows
-    if (wave == (i & 3) && i >= 1 && i - 1 < NB) {
+    if (wave == (i & 3) && i >= 1 && i - 1 < NB && !YS_ABLATE(1)) {
       const int bb = i - 1;
       const float* pl = sm.plane[bb & 1] + xr * SW + 2 * S * xc;
       float w[K + S];
@@ -260,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
     }
 
     // ---- inverse row stage (wave (i + 2) % 4): the block emitted in step i - 1 (slab block e = i - 6)
-    if (wave == ((i + 2) & 3) && i >= 6) {
+    if (wave == ((i + 2) & 3) && i >= 6 && !YS_ABLATE(1)) {
       const int e = i - 6;
       const float* src = sm.inv[(i - 1) & 1] + lane * PITCH;
       float re[K], im[K];
@@ -305,10 +356,41 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
     }
 
     // ---- staging, second half: the samples loaded at the top go to LDS for the next step's forward row stage
-    if (i < NB) {
-      float* pl = sm.plane[i & 1];
-      *reinterpret_cast<float4*>(pl + 4 * sg0) = st0.get(pk0);
-      if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = st1.get(pk1);
+    if constexpr (!LUM) {
+      if (i < NB) {
+        float* pl = sm.plane[i & 1];
+        *reinterpret_cast<float4*>(pl + 4 * sg0) = st0.get(pk0);
+        if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = st1.get(pk1);
+      }
+    } else {
+#pragma clang fp contract(off)
+      if (i < NB && lum_half >= 0) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int grp = lane + 64 * u;
+          if (grp < 4 * GRP_PER_ROW) {
+            const int brow = 4 * lum_half + grp / GRP_PER_ROW, col = 4 * (grp % GRP_PER_ROW);
+            float v[12], lv[4];
+            if (pkx[u]) {
+              px[u].get(v);
+            } else {  // frame edges: reflected single pixels (or nothing beyond the last active tile), loaded here
+              const T* rowp = base + (size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W * 3;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const bool need = col + j < sx_lim;
+                const T* q = rowp + (size_t)(need ? reflect_index(px0 + col + j, W) : 0) * 3;
+                v[3 * j] = need ? ld(q, 0) : 0.0f; v[3 * j + 1] = need ? ld(q, 1) : 0.0f; v[3 * j + 2] = need ? ld(q, 2) : 0.0f;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // same expression as lum_extract_vec4 (color.hip)
+              const float yv = YS_ABLATE(3) ? v[3 * j] + v[3 * j + 1] + v[3 * j + 2] : cA::rgb_to_lab_l(clip3(mk3(v[3 * j], v[3 * j + 1], v[3 * j + 2])));
+              lv[j] = YS_ABLATE(3) ? yv : tdk_log(fmaxf(lum_eps, yv));
+            }
+            *reinterpret_cast<float4*>(sm.plane[i & 1] + brow * SW + col) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+          }
+        }
+      }
     }
     __syncthreads();
   }

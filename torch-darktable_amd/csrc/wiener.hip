@@ -694,8 +694,18 @@ template <typename T>
 int launch_tiles_ys(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, hipStream_t st_, int nplanes) {
   const int vec_ok = W % 4 == 0 && (C == 1 ? tdk_aligned(in, 4 * sizeof(T)) : (C == 3 && tdk_aligned(in, 16)));
   static const ys::YParams yp = make_yparams();
-  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(256), 0, st_, in, slabs, W, H, C, c, vec_ok, g, sigmas, yp,
-             C == 1 ? (size_t)W * H : (size_t)0);
+  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T, false>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(256), 0, st_, in, slabs, W, H, C, c, vec_ok, g, sigmas,
+             yp, C == 1 ? (size_t)W * H : (size_t)0, 0.0f);
+  return TDK_OK;
+}
+
+// The tile kernel on the log-lightness of an interleaved RGB image, extracted on the fly (no plane in HBM).
+template <typename T>
+int launch_tiles_ys_lum(const T* rgb, float* slabs, int W, int H, const float* sigma, float eps, const Geom& g, hipStream_t st_) {
+  const int vec_ok = W % 4 == 0 && tdk_aligned(rgb, 16);
+  static const ys::YParams yp = make_yparams();
+  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T, true>), dim3((unsigned)(g.ngx * g.ngy)), dim3(256), 0, st_, rgb, slabs, W, H, 3, 0, vec_ok, g, sigma, yp, (size_t)0,
+             eps);
   return TDK_OK;
 }
 
@@ -727,12 +737,22 @@ int pick_group_width(int W, int H, int K, int ov, int nplanes, int per_cu) {
   return best;
 }
 
+// The tile kernels use the window as compile-time literals: true iff the table still matches make_window().
+template <int K> bool window_table_ok() {
+  static const bool ok = [] {
+    float w[32];
+    make_window(K, 0.3, w);
+    for (int i = 0; i < K; i++)
+      if (w[i] != WindowK<K>::w[i]) return false;
+    return true;
+  }();
+  return ok;
+}
+
 template <int K> WParams make_params(const Geom& g, int ov) {
   WParams prm = {};
   make_window(K, 0.3, prm.wf);
   make_window(K, 0.3, prm.wi);
-  for (int i = 0; i < K; i++)
-    if (prm.wf[i] != WindowK<K>::w[i] || prm.wi[i] != WindowK<K>::w[i]) abort();  // the compiled-in table no longer matches make_window()
   for (int r = 0; r < g.s; r++) {
     float m = 0.0f;
     for (int k = 0; k < ov; k++) m += prm.wf[r + k * g.s] * prm.wi[r + k * g.s];
@@ -776,6 +796,7 @@ inline unsigned stream_blocks(int64_t npix) {
 
 template <typename T, int K>
 int launch(const void* in, void* out, void* workspace, int W, int H, int C, int ov, const float* sigmas, hipStream_t st_) {
+  TDK_REQUIRE(window_table_ok<K>(), "tdk_wiener: the compiled-in window table does not match make_window()");
   const bool ysk = use_ystream(K, ov);
   const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, C == 3 ? 3 : 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, C == 3 ? 3 : 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
@@ -806,14 +827,26 @@ int launch(const void* in, void* out, void* workspace, int W, int H, int C, int 
 template <typename T, int K>
 int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_,
                          float* lum_out = nullptr, int lum_log = 0, float lum_eps = 1e-6f) {
+  TDK_REQUIRE(window_table_ok<K>(), "tdk_wiener: the compiled-in window table does not match make_window()");
   const bool ysk = use_ystream(K, ov);
   const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
-  int rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
-  if (rc != TDK_OK) return rc;
-  rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
+  int rc;
+  bool fused_lum = false;
+#ifdef TDK_EXPERIMENTS
+  // log-lightness extracted inside the tile kernel: measured SLOWER than the streaming extraction kernel + plane (the
+  // conversion's ~9 transcendentals per pixel cost the issue-bound tile kernel 53 us; the HBM-bound extraction kernel 22 us)
+  fused_lum = ysk && getenv("TDK_WIENER_FUSED_LUM") != nullptr;
+#endif
+  if (fused_lum) {
+    rc = launch_tiles_ys_lum<T>(reinterpret_cast<const T*>(rgb_in), slabs, W, H, sigma, eps, g, st_);
+  } else {
+    rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
+    if (rc != TDK_OK) return rc;
+    rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
+  }
   if (rc != TDK_OK) return rc;
   if ((W % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && (!lum_out || tdk_aligned(lum_out, 16)))
     TDK_LAUNCH("tdk_wiener(finish+modify)", (wiener_finish_modify<T, 4>), dim3((unsigned)tdk_div_up(W / 4, 256), (unsigned)(H < 32768 ? H : 32768)), dim3(256), 0, st_, slabs,

@@ -58,6 +58,7 @@ SIGNATURES = {
   'tdk_bilateral_rgb_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
   'tdk_bilateral_grid_size': (c_int, [c_int, c_int, c_float, c_float, C.POINTER(c_int)]),
   'tdk_bilateral_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),
+  'tdk_bilateral_select_path': (c_int, [c_int]),
   'tdk_bilateral': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
   'tdk_bilateral_rgb_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),
   'tdk_bilateral_rgb': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
