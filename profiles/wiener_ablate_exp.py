@@ -1,6 +1,7 @@
 """Experiment: where the y-streaming Wiener tile kernel spends its time.  Variant libraries built with
 -DTDK_EXPERIMENTS -DTDK_YS_ABLATE=n leave one part out (results are wrong, only the duration matters):
   1 no row stages   2 no column pipeline   3 log-lightness conversion replaced by a sum   4 no gains   5 no column FFTs / gains
+-DTDK_YS_TIMING=1 (variant 9, ys_timing.so) keeps everything and adds clock64() stamps per phase and wave of one workgroup.
     python profiles/wiener_ablate_exp.py build          # in the build container: variants/ys_ablate<n>.so + ys_full.so
     python profiles/wiener_ablate_exp.py variants/ys_*.so   # on the GPU box
 Each library is timed in its own process: tdk_wiener (fp32 plane) and tdk_wiener_log_luminance (fp16 RGB) at 12 MP."""
@@ -25,11 +26,11 @@ def build():
     out = ROOT / 'variants'
     out.mkdir(exist_ok=True)
     others = [str(o) for o in (PKG / 'build').glob('*.o') if o.stem != 'wiener']
-    for n in [0] + [int(a) for a in sys.argv[2:]] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 5]:
+    for n in [0] + [int(a) for a in sys.argv[2:]] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 5, 9]:
         obj = out / f'wiener_{n}.o'
-        flags = [f for f in b.CXXFLAGS] + (['-DTDK_EXPERIMENTS', f'-DTDK_YS_ABLATE={n}'] if n else [])
+        flags = [f for f in b.CXXFLAGS] + (['-DTDK_EXPERIMENTS', f'-DTDK_YS_ABLATE={n}'] if n not in (0, 9) else []) + (['-DTDK_EXPERIMENTS', '-DTDK_YS_TIMING=1'] if n == 9 else [])
         subprocess.run([b.HIPCC, *flags, '-c', str(PKG / 'csrc' / 'wiener.hip'), '-o', str(obj)], check=True)
-        lib = out / (f'ys_ablate{n}.so' if n else 'ys_full.so')
+        lib = out / ('ys_timing.so' if n == 9 else (f'ys_ablate{n}.so' if n else 'ys_full.so'))
         subprocess.run([b.HIPCC, '-shared', '-fPIC', f'--offload-arch={b.ARCH}', '-o', str(lib), *others, str(obj)], check=True)
         obj.unlink()
         print(lib)
@@ -65,6 +66,14 @@ def child(path):
         b.record()
         torch.cuda.synchronize()
         res[name + '_us'] = round(a.elapsed_time(b) / 20 * 1e3, 1)
+    if hasattr(lib, 'tdk_debug_ys_phase_cycles'):
+        buf = (C.c_ulonglong * 32)()
+        lib.tdk_debug_ys_phase_cycles(buf, 1)  # reset
+        runs['plane_f32']()
+        torch.cuda.synchronize()
+        lib.tdk_debug_ys_phase_cycles(buf, 1)
+        names = ['loads', 'column', 'fwd_row', 'inv_row', 'staging', 'barrier', 'empty']
+        res['cycles_of_workgroup_200'] = {f'wave{w_}': {names[k]: int(buf[w_ * 8 + k]) for k in range(7)} for w_ in range(4)}
     print(json.dumps(res))
 
 

@@ -27,6 +27,14 @@
 
 namespace ys {
 
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+// experiments: clock64() deltas per phase and wave of one workgroup, summed over its steps (profiles/wiener_ablate_exp.py)
+__device__ unsigned long long g_ys_phase_cycles[4][8];
+#define YS_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ys_acc[k] += t_ - ys_t0; ys_t0 = t_; } while (0)  // wave-uniform: lives in SGPRs
+#else
+#define YS_MARK(k)
+#endif
+
 #if defined(TDK_EXPERIMENTS) && defined(TDK_YS_ABLATE)
 #define YS_ABLATE(n) (TDK_YS_ABLATE == (n))  // timing-only builds (wrong results): profiles/wiener_ablate_exp.py
 #else
@@ -60,25 +68,121 @@ template <int CTRL> __device__ __forceinline__ float dpp0(float x) {  // DPP mov
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 
+using tdk_fft::fft_inreg_pk;
+using tdk_fft::v2f;
+
+// x * wf[y] and wf[y] * x + c with the window value as a scalar operand: the 32 values (16 distinct: the window is
+// symmetric) travel as 8 constant pairs
+__device__ __forceinline__ v2f win_scale(int y, v2f x) {
+  const int j = y < 16 ? y : 31 - y;
+  const v2f wp = {WindowK<32>::w[j & ~1], WindowK<32>::w[j | 1]};
+  return (j & 1) ? tdk_fft::pk_scale<1>(wp, x) : tdk_fft::pk_scale<0>(wp, x);
+}
+__device__ __forceinline__ v2f win_fma(int y, v2f x, v2f c) {
+  const int j = y < 16 ? y : 31 - y;
+  const v2f wp = {WindowK<32>::w[j & ~1], WindowK<32>::w[j | 1]};
+  return (j & 1) ? tdk_fft::pk_fma_s<1>(wp, x, c) : tdk_fft::pk_fma_s<0>(wp, x, c);
+}
+
+// Partner exchange of the gains step, in place: x <- x of lane ^ 1 in every lane except the two self-conjugate lanes of each
+// 32-lane slot, which keep their own value.  EXEC is narrowed to the exchanging lanes around the DPP moves (a lane that is
+// switched off keeps its register, and the moves that would read it are switched off too), which saves the select that
+// partner2() needs per value; one EXEC round trip serves a batch of up to 14 registers.  Only valid where EXEC is all ones
+// (the column stage sits under wave-uniform branches).
+#define YS_DPP1(r) "v_mov_b32_dpp %[" #r "], %[" #r "] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+template <int N> __device__ __forceinline__ void partner_swap(v2f* (&r)[N]) {
+  static_assert(N >= 1 && N <= 7, "at most 14 registers per batch (asm operand limit)");
+  constexpr unsigned long long EXCH = ~0x0000000300000003ull;
+  float v[14];
+#pragma unroll
+  for (int i = 0; i < N; i++) { v[2 * i] = r[i]->x; v[2 * i + 1] = r[i]->y; }
+#pragma unroll
+  for (int i = 2 * N; i < 14; i++) v[i] = 0.0f;
+  // s_nop 1: a VALU write needs two wait states before a DPP read of the same register
+  if constexpr (N == 7)
+    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) YS_DPP1(e) YS_DPP1(f) YS_DPP1(g) YS_DPP1(h) YS_DPP1(i) YS_DPP1(j)
+                 YS_DPP1(k) YS_DPP1(l) YS_DPP1(n) YS_DPP1(o) "s_mov_b64 exec, -1"
+                 : [a] "+v"(v[0]), [b] "+v"(v[1]), [c] "+v"(v[2]), [d] "+v"(v[3]), [e] "+v"(v[4]), [f] "+v"(v[5]), [g] "+v"(v[6]), [h] "+v"(v[7]), [i] "+v"(v[8]),
+                   [j] "+v"(v[9]), [k] "+v"(v[10]), [l] "+v"(v[11]), [n] "+v"(v[12]), [o] "+v"(v[13])
+                 : [m] "s"(EXCH));
+  else if constexpr (N == 2)
+    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) "s_mov_b64 exec, -1"
+                 : [a] "+v"(v[0]), [b] "+v"(v[1]), [c] "+v"(v[2]), [d] "+v"(v[3])
+                 : [m] "s"(EXCH));
+  else
+    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) "s_mov_b64 exec, -1" : [a] "+v"(v[0]), [b] "+v"(v[1]) : [m] "s"(EXCH));
+#pragma unroll
+  for (int i = 0; i < N; i++) *r[i] = v2f{v[2 * i], v[2 * i + 1]};
+}
+
+// wiener_gains on {re, im} pairs (same arithmetic; see wiener_gains in wiener.hip for the derivation).  With u = Z[k], p = Z[-k]
+// (from the partner lane): a2 = u + conj(p) = 2A, d = u - conj(p) = 2 i B, and
+//   Z'[k] = ga a2 + gb d,   the partner's Z'[-k] = conj(ga a2 - gb d).
+// Three phases: (1) every register -k (k = 1 .. 15) is swapped with the partner lane in place (its own value is only
+// needed there), k = 0 and 16 through copies; (2) the arithmetic, free of cross-lane operations, so the scheduler can
+// interleave the 17 chains; (3) the by-products travel back.
+__device__ __forceinline__ void wiener_gains_pk(v2f (&z)[32], float sig2) {
+  constexpr float GSCALE = 0.5f / (float)(32 * 32);
+  float sgs = -4.0f * sig2 * GSCALE;
+  asm volatile("" : "+v"(sgs));
+  v2f p0 = z[0], p16 = z[16];
+  {
+    v2f* r1[7] = {&z[31], &z[30], &z[29], &z[28], &z[27], &z[26], &z[25]};
+    partner_swap(r1);
+    v2f* r2[7] = {&z[24], &z[23], &z[22], &z[21], &z[20], &z[19], &z[18]};
+    partner_swap(r2);
+    v2f* r3[2] = {&z[17], &p0};
+    partner_swap(r3);
+    v2f* r4[1] = {&p16};
+    partner_swap(r4);
+  }
+#pragma unroll
+  for (int k = 0; k <= 16; k++) {
+    const int k2 = (32 - k) & 31;
+    const v2f u = z[k];
+    const v2f p = k == 0 ? p0 : (k == 16 ? p16 : z[k2]);
+    v2f a2, d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(a2) : "v"(u), "v"(p));  // u + conj(p)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(u), "v"(p));   // u - conj(p)
+    const float pa4 = __builtin_fmaf(a2.y, a2.y, __builtin_fmaf(a2.x, a2.x, 4e-15f)), pb4 = __builtin_fmaf(d.y, d.y, __builtin_fmaf(d.x, d.x, 4e-15f));
+    v2f gg;  // {ga, gb}
+    gg.x = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pa4), GSCALE), 0.0f);
+    gg.y = fmaxf(__builtin_fmaf(sgs, __builtin_amdgcn_rcpf(pb4), GSCALE), 0.0f);
+    v2f t, zk;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(gg), "v"(d));              // gb d
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(zk) : "v"(gg), "v"(a2), "v"(t));            // ga a2 + gb d
+    z[k] = zk;
+    if (k2 != k) {
+      v2f w;
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[1,0,0]" : "=v"(w) : "v"(gg), "v"(a2), "v"(t));  // conj(ga a2 - gb d)
+      z[k2] = w;
+    }
+  }
+  {
+    v2f* r1[7] = {&z[31], &z[30], &z[29], &z[28], &z[27], &z[26], &z[25]};
+    partner_swap(r1);
+    v2f* r2[7] = {&z[24], &z[23], &z[22], &z[21], &z[20], &z[19], &z[18]};
+    partner_swap(r2);
+    v2f* r3[1] = {&z[17]};
+    partner_swap(r3);
+  }
+}
+#undef YS_DPP1
+
 // Raw staging registers: the global loads of a step's samples are issued at the top of the step and only converted /
 // written to LDS at its bottom, so nothing waits on them.
 template <typename T> struct Raw4;
 template <> struct Raw4<float> {
-  float v[4];
-  __device__ __forceinline__ void load4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  __device__ __forceinline__ void load1(int j, const float* p) { v[j] = *p; }
-  __device__ __forceinline__ void zero(int j) { v[j] = 0.0f; }
-  __device__ __forceinline__ float4 get(bool) const { return make_float4(v[0], v[1], v[2], v[3]); }
+  float4 v;
+  __device__ __forceinline__ void load4(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ float4 get() const { return v; }
 };
 template <> struct Raw4<__half> {
-  unsigned v[4];  // vector path: two packed pairs in v[0], v[1]; scalar path: one sample per register
-  __device__ __forceinline__ void load4(const __half* p) { const uint2 t = *reinterpret_cast<const uint2*>(p); v[0] = t.x; v[1] = t.y; }
-  __device__ __forceinline__ void load1(int j, const __half* p) { v[j] = *reinterpret_cast<const unsigned short*>(p); }
-  __device__ __forceinline__ void zero(int j) { v[j] = 0u; }
-  __device__ __forceinline__ float4 get(bool packed) const {
+  uint2 v;
+  __device__ __forceinline__ void load4(const __half* p) { v = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ float4 get() const {
     auto h = [](unsigned bits) { return __half2float(__ushort_as_half((unsigned short)bits)); };
-    if (packed) return make_float4(h(v[0] & 0xffffu), h(v[0] >> 16), h(v[1] & 0xffffu), h(v[1] >> 16));
-    return make_float4(h(v[0]), h(v[1]), h(v[2]), h(v[3]));
+    return make_float4(h(v.x & 0xffffu), h(v.x >> 16), h(v.y & 0xffffu), h(v.y >> 16));
   }
 };
 
@@ -143,189 +247,61 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
   const bool has1 = lane < GRP_PER_WAVE - 64;
   const bool vec = vec_ok && C == 1;
 
-  float wr[32], wi[32];      // R[y][kx] of the current window (tile-relative row y)
-  float cr[24], ci[24];      // carried (unfinished) rows of the overlap-add across tile rows, tile-relative
+  v2f win[32];    // R[y][kx] of the current window (tile-relative row y), {re, im} register pairs
+  v2f carry[24];  // carried (unfinished) rows of the overlap-add across tile rows, tile-relative
 #pragma unroll
-  for (int k = 0; k < 32; k++) wr[k] = wi[k] = 0.0f;
+  for (int k = 0; k < 32; k++) win[k] = v2f{0.0f, 0.0f};
 #pragma unroll
-  for (int k = 0; k < 24; k++) cr[k] = ci[k] = 0.0f;
+  for (int k = 0; k < 24; k++) carry[k] = v2f{0.0f, 0.0f};
 
-  // 4 samples of block q (image rows 8 q - 24 ...), strip columns 4 (grp % 38) ...: issue the loads; true = packed 16-B / 8-B load
+  // 4 samples of block q (image rows 8 q - 24 ...), strip columns 4 (grp % 38) ...  fetch() issues the one 16-B / 8-B load
+  // of an in-frame group at the top of a step; a group that touches the frame edge (reflected single samples, or nothing
+  // beyond the last active tile) is read by fetch_edge() at the bottom instead.  Keeping the two apart matters: loads into the
+  // same registers from both paths would make the compiler drain vmcnt between them -- behind the step's slab stores.
   auto fetch = [&](int grp, int q, Raw4<T>& raw) -> bool {
+    const int brow = grp / GRP_PER_ROW, x = px0 + 4 * (grp - brow * GRP_PER_ROW);
+    if (!(vec && x >= 0 && x + 4 <= W)) return false;
+    raw.load4(base + (size_t)reflect_index(8 * q + brow + g.jmin * S, H) * W + x);
+    return true;
+  };
+  auto fetch_edge = [&](int grp, int q) -> float4 {
     const int brow = grp / GRP_PER_ROW, col = 4 * (grp - brow * GRP_PER_ROW);
-    const int y = reflect_index(8 * q + brow + g.jmin * S, H);
-    const T* rowp = base + (size_t)y * W * C;
-    const int x = px0 + col;
-    if (vec && x >= 0 && x + 4 <= W) {
-      raw.load4(rowp + x);
-      return true;
-    }
+    const T* rowp = base + (size_t)reflect_index(8 * q + brow + g.jmin * S, H) * W * C;
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (col + j < sx_lim) raw.load1(j, rowp + (size_t)reflect_index(x + j, W) * C + chan);
-      else raw.zero(j);
-    }
-    return false;
+    for (int j = 0; j < 4; j++) v[j] = (col + j < sx_lim) ? ld(rowp, (size_t)reflect_index(px0 + col + j, W) * C + chan) : 0.0f;
+    return make_float4(v[0], v[1], v[2], v[3]);
   };
-  auto emit = [&](float* dst, const float (&or_)[8], const float (&oi_)[8]) {
+  auto emit = [&](float* dst, const v2f (&o)[8]) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) *reinterpret_cast<float2*>(dst + row_of(0, r) * PITCH) = make_float2(or_[r], oi_[r]);
+    for (int r = 0; r < 8; r++) *reinterpret_cast<v2f*>(dst + row_of(0, r) * PITCH) = o[r];
   };
 
+  // The per-lane constants above come from global loads (kernel-argument tables indexed by lane).  Retire them here: a
+  // first use inside the loop makes the compiler wait with vmcnt(0) there in EVERY step -- behind the step's staging loads,
+  // whose latency the whole design is built to hide.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::"v"(whr), "v"(whi));
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+  unsigned long long ys_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ys_t0 = __builtin_readcyclecounter();
+#endif
   for (int i = 0; i < NB + 6; i++) {
-    // ---- staging, first half: issue the global loads of block i (consumed at the bottom of the step)
-    Raw4<T> st0, st1;
-    RawRgb4<T> px[3];
-    bool pk0 = false, pk1 = false, pkx[3] = {false, false, false};
-    const int lum_half = wave == ((i + 1) & 3) ? 0 : (wave == ((i + 3) & 3) ? 1 : -1);  // LUM: this wave converts block rows 4 h .. 4 h + 3
-    if constexpr (!LUM) {
-      if (i < NB) {
-        pk0 = fetch(sg0, t0 + i, st0);
-        if (has1) pk1 = fetch(sg1, t0 + i, st1);
-      }
-    } else {
-      if (i < NB && lum_half >= 0) {
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-          const int grp = lane + 64 * u;  // of the 4 x 38 groups of this half block
-          if (grp < 4 * GRP_PER_ROW) {
-            const int brow = 4 * lum_half + grp / GRP_PER_ROW, x = px0 + 4 * (grp % GRP_PER_ROW);
-            if (vec_ok && x >= 0 && x + 4 <= W) {
-              px[u].load(base + ((size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W + x) * 3);
-              pkx[u] = true;
-            }
-          }
-        }
-      }
-    }
-
-    // ---- column stage: block b = i - 2 arrives; tile row t0 + b - 3 is complete from b = 3 on; after the last
-    // block the three carried blocks leave as they are (partial sums for the seam with the next strip segment)
-    const int b = i - 2;
-    if (b >= 0 && b < NB) {
-      // the window moves down one block: rows 8 .. 31 become rows 0 .. 23 (48 register moves: cheaper than what the
-      // compiler makes of a code variant per window phase), the arriving block becomes rows 24 .. 31
-#pragma unroll
-      for (int y = 0; y < 24; y++) { wr[y] = wr[y + 8]; wi[y] = wi[y + 8]; }
-      const float* f = sm.fwd[b & 1] + col_off;
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const float2 v = *reinterpret_cast<const float2*>(f + row_of(0, r) * PITCH);
-        wr[24 + r] = v.x;
-        wi[24 + r] = v.y;
-      }
-      if (b >= 3 && !YS_ABLATE(2)) {
-        float sa = 0.0f, sb = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float2 t = *reinterpret_cast<const float2*>(sm.meta[(b - q) & 7] + 2 * yc);
-          sa += t.x;
-          sb += t.y;
-        }
-        const float mean_a = ya ? sa * (1.0f / (K * K)) : 0.0f, mean_b = yb ? sb * (1.0f / (K * K)) : 0.0f;
-        const float mr = mean_a * whr - mean_b * whi, mi = mean_a * whi + mean_b * whr;  // (mean_a + i mean_b) W[kx]
-        float zr[32], zi[32];
-#pragma unroll
-        for (int y = 0; y < 32; y++) {
-          zr[y] = (wr[y] - mr) * WindowK<32>::w[y];
-          zi[y] = (wi[y] - mi) * WindowK<32>::w[y];
-        }
-        if (!YS_ABLATE(5)) fft_inreg<32, false>(zr, zi);
-        if (!YS_ABLATE(4) && !YS_ABLATE(5)) wiener_gains<32>(zr, zi, sig2);
-        if (!YS_ABLATE(5)) fft_inreg<32, true>(zr, zi);
-        // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
-        const float ar = mr * (1.0f / K), ai = mi * (1.0f / K);
-        {
-          float or_[8], oi_[8];
-#pragma unroll
-          for (int y = 0; y < 8; y++) {
-            or_[y] = __builtin_fmaf(WindowK<32>::w[y], __builtin_fmaf(WindowK<32>::w[y], ar, zr[y]), cr[y]);
-            oi_[y] = __builtin_fmaf(WindowK<32>::w[y], __builtin_fmaf(WindowK<32>::w[y], ai, zi[y]), ci[y]);
-          }
-          emit(sm.inv[i & 1] + col_off, or_, oi_);
-        }
-        // the carried rows move up one block while they are updated: row y takes the sum of row y + 8.  In this order every
-        // register is read before it is rewritten; the scheduling barriers keep the order, so the move costs no copies
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
-          cr[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]), cr[y + 8]);
-          ci[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]), ci[y + 8]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 8; y < 16; y++) {
-          cr[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]), cr[y + 8]);
-          ci[y] = __builtin_fmaf(WindowK<32>::w[y + 8], __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]), ci[y + 8]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 16; y < 24; y++) {
-          cr[y] = WindowK<32>::w[y + 8] * __builtin_fmaf(WindowK<32>::w[y + 8], ar, zr[y + 8]);
-          ci[y] = WindowK<32>::w[y + 8] * __builtin_fmaf(WindowK<32>::w[y + 8], ai, zi[y + 8]);
-        }
-      }
-    } else if (b >= NB && b < NB + 3) {
-      float or_[8], oi_[8];
-#pragma unroll
-      for (int y = 0; y < 8; y++) { or_[y] = cr[y]; oi_[y] = ci[y]; }
-      emit(sm.inv[i & 1] + col_off, or_, oi_);
-#pragma unroll
-      for (int y = 0; y < 16; y++) { cr[y] = cr[y + 8]; ci[y] = ci[y + 8]; }
-    }
-
-    // ---- forward row stage (wave i % 4): block i - 1 from the staging buffer -> R rows
-    if (wave == (i & 3) && i >= 1 && i - 1 < NB && !YS_ABLATE(1)) {
-      const int bb = i - 1;
-      const float* pl = sm.plane[bb & 1] + xr * SW + 2 * S * xc;
-      float w[K + S];
-#pragma unroll
-      for (int k = 0; k < K + S; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(pl + k);
-        w[k] = t.x; w[k + 1] = t.y; w[k + 2] = t.z; w[k + 3] = t.w;
-      }
-      float head = 0.0f, mid = 0.0f, tail = 0.0f;
-#pragma unroll
-      for (int k = 0; k < S; k++) head += w[k];
-#pragma unroll
-      for (int k = S; k < K; k++) mid += w[k];
-#pragma unroll
-      for (int k = K; k < K + S; k++) tail += w[k];
-      // block sums under tile a / tile b: over the 8 block rows = lane bits 0, 4, 5
-      float ba = xa ? head + mid : 0.0f, bb_ = xb ? mid + tail : 0.0f;
-      ba += dpp0<0xB1>(ba); bb_ += dpp0<0xB1>(bb_);  // quad_perm [1,0,3,2]
-      ba += __shfl_xor(ba, 16, 64); bb_ += __shfl_xor(bb_, 16, 64);
-      ba += __shfl_xor(ba, 32, 64); bb_ += __shfl_xor(bb_, 32, 64);
-      if (xr == 0) *reinterpret_cast<float2*>(sm.meta[bb & 7] + 2 * xc) = make_float2(ba, bb_);
-      float re[K], im[K];
-      const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        re[k] = (w[k] * fa) * WindowK<32>::w[k];
-        im[k] = (w[k + S] * fb) * WindowK<32>::w[k];
-      }
-      fft_inreg<32, false>(re, im);
-      float* dst = sm.fwd[bb & 1] + lane * PITCH;
-#pragma unroll
-      for (int k = 0; k < K; k += 2) *reinterpret_cast<float4*>(dst + 2 * k) = make_float4(re[k], im[k], re[k + 1], im[k + 1]);
-    }
-
     // ---- inverse row stage (wave (i + 2) % 4): the block emitted in step i - 1 (slab block e = i - 6)
+    // (first in the step: its slab stores are then long complete when the step's global loads are awaited -- VMEM operations
+    // retire in order, and the compiler's conservative vmcnt(0) would otherwise expose the store latency every step)
     if (wave == ((i + 2) & 3) && i >= 6 && !YS_ABLATE(1)) {
       const int e = i - 6;
       const float* src = sm.inv[(i - 1) & 1] + lane * PITCH;
-      float re[K], im[K];
+      v2f z[K];
 #pragma unroll
-      for (int k = 0; k < K; k += 2) {
-        const float4 t = *reinterpret_cast<const float4*>(src + 2 * k);
-        re[k] = t.x; im[k] = t.y; re[k + 1] = t.z; im[k + 1] = t.w;
-      }
-      fft_inreg<32, true>(re, im);  // re = row of tile a, im = row of tile b (columns S further)
+      for (int k = 0; k < K; k++) z[k] = *reinterpret_cast<const v2f*>(src + 2 * k);
+      fft_inreg_pk<32, true>(z);  // .x = row of tile a, .y = row of tile b (columns S further)
       float s_[K + S];
 #pragma unroll
       for (int u = 0; u < K + S; u++) {
-        float v = (u < K) ? re[u] * WindowK<32>::w[u] : 0.0f;
-        if (u >= S) v = (u < K) ? __builtin_fmaf(im[u - S], WindowK<32>::w[u - S], v) : im[u - S] * WindowK<32>::w[u - S];
+        float v = (u < K) ? z[u].x * WindowK<32>::w[u] : 0.0f;
+        if (u >= S) v = (u < K) ? __builtin_fmaf(z[u - S].y, WindowK<32>::w[u - S], v) : z[u - S].y * WindowK<32>::w[u - S];
         s_[u] = v;
       }
       // overlap-add along x across tile pairs: pair c's samples [16, 32) belong to pair c + 1's [0, 16), its [32, 40) to
@@ -355,12 +331,131 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
       }
     }
 
+    YS_MARK(3);  // inverse row stage
+    // ---- staging, first half: issue the global loads of block i (consumed at the bottom of the step)
+    Raw4<T> st0, st1;
+    RawRgb4<T> px[3];
+    bool pk0 = false, pk1 = false, pkx[3] = {false, false, false};
+    const int lum_half = wave == ((i + 1) & 3) ? 0 : (wave == ((i + 3) & 3) ? 1 : -1);  // LUM: this wave converts block rows 4 h .. 4 h + 3
+    if constexpr (!LUM) {
+      if (i < NB) {
+        pk0 = fetch(sg0, t0 + i, st0);
+        if (has1) pk1 = fetch(sg1, t0 + i, st1);
+      }
+    } else {
+      if (i < NB && lum_half >= 0) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int grp = lane + 64 * u;  // of the 4 x 38 groups of this half block
+          if (grp < 4 * GRP_PER_ROW) {
+            const int brow = 4 * lum_half + grp / GRP_PER_ROW, x = px0 + 4 * (grp % GRP_PER_ROW);
+            if (vec_ok && x >= 0 && x + 4 <= W) {
+              px[u].load(base + ((size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W + x) * 3);
+              pkx[u] = true;
+            }
+          }
+        }
+      }
+    }
+
+    YS_MARK(0);  // staging loads issued
+    // ---- column stage: block b = i - 2 arrives; tile row t0 + b - 3 is complete from b = 3 on; after the last
+    // block the three carried blocks leave as they are (partial sums for the seam with the next strip segment)
+    const int b = i - 2;
+    if (b >= 0 && b < NB) {
+      // the window moves down one block: rows 8 .. 31 become rows 0 .. 23 (24 pair moves: cheaper than what the compiler
+      // makes of a code variant per window phase), the arriving block becomes rows 24 .. 31
+#pragma unroll
+      for (int y = 0; y < 24; y++) win[y] = win[y + 8];
+      const float* f = sm.fwd[b & 1] + col_off;
+#pragma unroll
+      for (int r = 0; r < 8; r++) win[24 + r] = *reinterpret_cast<const v2f*>(f + row_of(0, r) * PITCH);
+      if (b >= 3 && !YS_ABLATE(2)) {
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float2 t = *reinterpret_cast<const float2*>(sm.meta[(b - q) & 7] + 2 * yc);
+          sa += t.x;
+          sb += t.y;
+        }
+        const float mean_a = ya ? sa * (1.0f / (K * K)) : 0.0f, mean_b = yb ? sb * (1.0f / (K * K)) : 0.0f;
+        const v2f m = {mean_a * whr - mean_b * whi, mean_a * whi + mean_b * whr};  // (mean_a + i mean_b) W[kx]
+        v2f z[32];
+#pragma unroll
+        for (int y = 0; y < 32; y++) z[y] = win_scale(y, win[y] - m);  // (R - mean W) wf[y]
+        if (!YS_ABLATE(5)) fft_inreg_pk<32, false>(z);
+        if (!YS_ABLATE(4) && !YS_ABLATE(5)) wiener_gains_pk(z, sig2);
+        if (!YS_ABLATE(5)) fft_inreg_pk<32, true>(z);
+        // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
+        const v2f ma = m * (1.0f / K);
+        {
+          v2f o[8];
+#pragma unroll
+          for (int y = 0; y < 8; y++) o[y] = win_fma(y, win_fma(y, ma, z[y]), carry[y]);
+          emit(sm.inv[i & 1] + col_off, o);
+        }
+        // the carried rows move up one block while they are updated: row y takes the sum of row y + 8.  In this order every
+        // register is read before it is rewritten; the scheduling barriers keep the order, so the move costs no copies
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 8; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 8; y < 16; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 16; y < 24; y++) carry[y] = win_scale(y + 8, win_fma(y + 8, ma, z[y + 8]));
+      }
+    } else if (b >= NB && b < NB + 3) {
+      v2f o[8];
+#pragma unroll
+      for (int y = 0; y < 8; y++) o[y] = carry[y];
+      emit(sm.inv[i & 1] + col_off, o);
+#pragma unroll
+      for (int y = 0; y < 16; y++) carry[y] = carry[y + 8];
+    }
+
+    YS_MARK(1);  // column stage
+    // ---- forward row stage (wave i % 4): block i - 1 from the staging buffer -> R rows
+    if (wave == (i & 3) && i >= 1 && i - 1 < NB && !YS_ABLATE(1)) {
+      const int bb = i - 1;
+      const float* pl = sm.plane[bb & 1] + xr * SW + 2 * S * xc;
+      float w[K + S];
+#pragma unroll
+      for (int k = 0; k < K + S; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(pl + k);
+        w[k] = t.x; w[k + 1] = t.y; w[k + 2] = t.z; w[k + 3] = t.w;
+      }
+      float head = 0.0f, mid = 0.0f, tail = 0.0f;
+#pragma unroll
+      for (int k = 0; k < S; k++) head += w[k];
+#pragma unroll
+      for (int k = S; k < K; k++) mid += w[k];
+#pragma unroll
+      for (int k = K; k < K + S; k++) tail += w[k];
+      // block sums under tile a / tile b: over the 8 block rows = lane bits 0, 4, 5
+      float ba = xa ? head + mid : 0.0f, bb_ = xb ? mid + tail : 0.0f;
+      ba += dpp0<0xB1>(ba); bb_ += dpp0<0xB1>(bb_);  // quad_perm [1,0,3,2]
+      ba += __shfl_xor(ba, 16, 64); bb_ += __shfl_xor(bb_, 16, 64);
+      ba += __shfl_xor(ba, 32, 64); bb_ += __shfl_xor(bb_, 32, 64);
+      if (xr == 0) *reinterpret_cast<float2*>(sm.meta[bb & 7] + 2 * xc) = make_float2(ba, bb_);
+      v2f z[K];
+      const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; k++) z[k] = v2f{(w[k] * fa) * WindowK<32>::w[k], (w[k + S] * fb) * WindowK<32>::w[k]};
+      fft_inreg_pk<32, false>(z);
+      float* dst = sm.fwd[bb & 1] + lane * PITCH;
+#pragma unroll
+      for (int k = 0; k < K; k++) *reinterpret_cast<v2f*>(dst + 2 * k) = z[k];
+    }
+
+    YS_MARK(2);  // forward row stage
     // ---- staging, second half: the samples loaded at the top go to LDS for the next step's forward row stage
     if constexpr (!LUM) {
       if (i < NB) {
         float* pl = sm.plane[i & 1];
-        *reinterpret_cast<float4*>(pl + 4 * sg0) = st0.get(pk0);
-        if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = st1.get(pk1);
+        *reinterpret_cast<float4*>(pl + 4 * sg0) = pk0 ? st0.get() : fetch_edge(sg0, t0 + i);
+        if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = pk1 ? st1.get() : fetch_edge(sg1, t0 + i);
       }
     } else {
 #pragma clang fp contract(off)
@@ -392,8 +487,20 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
         }
       }
     }
+    // Every global operation of the step has retired by now (the stores were issued at its top, the loads are consumed just
+    // above).  Saying so explicitly keeps the compiler from placing its own vmcnt(0) at the top of the next step, right
+    // behind the next slab stores, where it would expose their latency (its scoreboard cannot see that the load and
+    // the use of the staging registers sit under the same condition).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+    YS_MARK(4);  // staging conversion / store
     __syncthreads();
+    YS_MARK(5);  // barrier
+    YS_MARK(6);  // nothing: the cost of a mark itself
   }
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+  if (lane == 0 && blockIdx.x == 200)
+    for (int k = 0; k < 7; k++) g_ys_phase_cycles[wave][k] += ys_acc[k];
+#endif
 }
 
 }  // namespace ys

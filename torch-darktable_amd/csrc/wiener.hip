@@ -45,6 +45,7 @@
 
 #include "tdk_color.h"
 #include "tdk_wave_fft.h"
+#include "tdk_wave_fft_pk.h"
 
 #pragma clang fp contract(fast)
 
@@ -858,6 +859,14 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 }
 
 }  // namespace
+
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+TDK_EXPORT int tdk_debug_ys_phase_cycles(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ys::g_ys_phase_cycles), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ys::g_ys_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 TDK_EXPORT size_t tdk_wiener_workspace_bytes(int width, int height, int channels, int tile_size, int overlap_factor) {
   if (width <= 0 || height <= 0 || !(tile_size == 16 || tile_size == 32) || !(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8)) return 0;
