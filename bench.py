@@ -199,6 +199,23 @@ def algorithmic_bytes_per_px(kernel: str, s: int) -> float | None:
     return table.get(kernel)
 
 
+# Bytes ONE LAUNCH of a kernel has to move per pixel (its own compulsory reads + writes; s = bytes per stored sample):
+# what the kernel's HBM time is priced on.  The op-boundary numbers above are what the Python-wrapper stage would move.
+def launch_bytes_per_px(kernel: str, s: int) -> float | None:
+    table = {
+        'tdk_rcd': 1 * s + 3 * s,
+        'tdk_compute_luminance': 3 * s + 4,                    # RGB in, fp32 (log-)lightness plane out
+        'tdk_wiener(tiles)': 4 + 4,                            # fp32 plane in, the denoised plane's sums out (fp32 slabs)
+        'tdk_wiener(finish+modify)': 4 + 3 * s + 3 * s + 4,    # sums in, RGB in, RGB out, fp32 lightness of the result out
+        'tdk_wiener(finish)': 4 + 1 * s,
+        'tdk_bilateral(tiles)': 4 + 3 * s + 3 * s,             # fp32 lightness in, RGB in, RGB out
+        'tdk_tonemap': 3 * s + 3,
+        'tdk_image_metrics_accumulate': 3 * s / 64.0,          # stride-8 sample grid
+        'tdk_image_metrics_finish': 0.0,
+    }
+    return table.get(kernel)
+
+
 def build_pipeline(td, dev, w, h, storage, workload):
     import torch
 
@@ -418,34 +435,64 @@ def main(argv=None):
         stage_ms = {k: round(ms / frames, 4) for k, (c, ms) in sorted(table.items(), key=lambda kv: -kv[1][1])}  # from the untimed pass
         cnt, ms = report[dom]  # the dominant kernel, timed live in the timed region
         avg_s = ms / cnt / 1e3
-        bpp = algorithmic_bytes_per_px(dom, sbytes)
-        achieved = (bpp * w * h / avg_s / 1e9) if bpp else None
-        traffic, valu, captured_at = None, None, None
+        lbpp = launch_bytes_per_px(dom, sbytes) or algorithmic_bytes_per_px(dom, sbytes)
+        op_bpp = algorithmic_bytes_per_px(dom, sbytes)
+        achieved = (lbpp * w * h / avg_s / 1e9) if lbpp else None
+        hbm_time_s = lbpp * w * h / (HBM_PEAK_GBS * 1e9) if lbpp else None
+        captured, valu, composite = None, None, None
         tfile = ROOT / 'profiles' / 'traffic.json'  # written by profiles/collect_traffic.py from rocprofv3 --pmc passes
         if tfile.exists() and (w, h, storage, args.workload) == (W12, H12, 'f16', 'isp'):
             tj = json.loads(tfile.read_text())
-            traffic = tj.get(dom)
-            captured_at = tj.get('_git')
-            insts = tj.get('_valu', {}).get(dom)    # SQ_INSTS_VALU: wave-instructions per launch (PMC pass)
-            trans = tj.get('_trans', {}).get(dom)   # of which transcendental (static share of the kernel's ISA x SQ_INSTS_VALU)
-            if insts:
-                # issue cycles per launch: plain instructions 2, transcendentals 8 (see the constants above)
-                cyc = insts * VALU_CYCLES_PLAIN + (trans or 0) * (VALU_CYCLES_TRANS - VALU_CYCLES_PLAIN)
-                floor_s = cyc / (VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ * 1e9)
-                valu = {'wave_insts_per_launch': insts, 'transcendental_insts_per_launch': trans,
-                        'achieved_Ginst_per_s': round(insts / avg_s / 1e9, 1), 'peak_Ginst_per_s': round(VALU_PEAK_GINST, 1),
-                        'alu_floor_us': round(floor_s * 1e6, 2), 'issue_frac': round(floor_s / avg_s, 4),
-                        'note': 'vector-ALU issue floor of this launch (2 cycles per wave64 instruction on a SIMD-32, 8 for transcendentals) over its '
-                                'measured duration; the kernel is FP32-vector / latency bound, the HBM figures above are reported because the contract asks for them'}
+
+            def alu_floor_s(kernel):
+                """Issue floor of one launch from the captured counters: plain wave64 instructions 2 SIMD cycles, packed fp32
+                (two operations per lane) 4, transcendentals 8."""
+                insts = tj.get('_valu', {}).get(kernel)
+                if not insts:
+                    return None
+                trans, packed = tj.get('_trans', {}).get(kernel) or 0, tj.get('_packed', {}).get(kernel) or 0
+                cyc = insts * VALU_CYCLES_PLAIN + trans * (VALU_CYCLES_TRANS - VALU_CYCLES_PLAIN) + packed * VALU_CYCLES_PLAIN
+                return cyc / (VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ * 1e9)
+
+            captured = {'hbm_bytes_per_launch': tj.get(dom), 'git': tj.get('_git'), 'source': 'profiles/traffic.json (rocprofv3 --pmc passes, not this run)'}
+            floor_s = alu_floor_s(dom)
+            if floor_s:
+                valu = {'wave_insts_per_launch': tj['_valu'][dom], 'transcendental_insts_per_launch': tj.get('_trans', {}).get(dom),
+                        'packed_fp32_insts_per_launch': tj.get('_packed', {}).get(dom),
+                        'achieved_Ginst_per_s': round(tj['_valu'][dom] / avg_s / 1e9, 1), 'peak_Ginst_per_s': round(VALU_PEAK_GINST, 1),
+                        'alu_floor_us': round(floor_s * 1e6, 2), 'issue_frac': round(floor_s / avg_s, 4), 'counters_captured_at_git': tj.get('_git')}
+            # composite floor of the whole frame: every kernel at the larger of its HBM time and its issue floor
+            comp_us, parts = 0.0, {}
+            for k, (c, ms_k) in table.items():
+                kb = launch_bytes_per_px(k, sbytes)
+                t_hbm = (kb * w * h / (HBM_PEAK_GBS * 1e9)) if kb else 0.0
+                t_alu = alu_floor_s(k) or 0.0
+                per_frame = max(t_hbm, t_alu) * c / frames
+                parts[k] = {'hbm_us': round(t_hbm * 1e6, 1), 'alu_floor_us': round(t_alu * 1e6, 1), 'measured_us': round(ms_k / c * 1e3, 1), 'launches_per_frame': c / frames}
+                comp_us += per_frame * 1e6
+            frame_us = elapsed / (frames * args.steps) * 1e6
+            composite = {'composite_floor_us_per_frame': round(comp_us, 1), 'measured_us_per_frame': round(frame_us, 1),
+                         'frac_of_composite': round(comp_us / frame_us, 4), 'kernels': parts,
+                         'note': 'sum over the kernels of a frame of max(HBM time of the launch bytes at 8 TB/s, issue floor from the captured counters)'}
+        bound = 'hbm'
+        frac = round(achieved / HBM_PEAK_GBS, 5) if achieved else None
+        if valu and hbm_time_s and valu['alu_floor_us'] * 1e-6 > hbm_time_s:
+            bound, frac = 'valu', valu['issue_frac']  # the kernel cannot go faster than its instruction issue: that is its roofline
+        alone_s = table[dom][1] / table[dom][0] / 1e3
         roofline = {
-            'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None, 'traffic': traffic, 'traffic_captured_at_git': captured_at,
-            'measured_traffic_GBps': round(traffic / avg_s / 1e9, 1) if traffic else None,
-            'avg_launch_us': round(avg_s * 1e6, 2), 'launches': cnt, 'algorithmic_bytes_per_launch': int(bpp * w * h) if bpp else None,
+            'kernel': dom, 'bound': bound, 'frac': frac,
+            'frac_means': ('vector-ALU issue floor / measured launch time (the HBM figures follow as hbm_*)' if bound == 'valu'
+                           else 'achieved / peak HBM bandwidth on the bytes this launch has to move'),
+            'achieved': round(achieved, 2) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'hbm_frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+            'algorithmic_bytes_per_launch': int(lbpp * w * h) if lbpp else None,
+            'op_boundary_bytes_per_launch': int(op_bpp * w * h) if op_bpp else None,
+            'traffic': captured['hbm_bytes_per_launch'] if captured else None, 'traffic_captured': captured,
+            'avg_launch_us': round(avg_s * 1e6, 2), 'launches': cnt,
             # the same kernel with the GPU to itself (untimed serial pass): in the timed region frames on the other stream(s) share the CUs with it
-            'avg_launch_us_alone': round(table[dom][1] / table[dom][0] * 1e3, 2),
-            'frac_alone': round(bpp * w * h / (table[dom][1] / table[dom][0] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if bpp else None,
-            'kernel_launches_in_timed_region': launches_total, 'valu': valu,
+            'avg_launch_us_alone': round(alone_s * 1e6, 2),
+            'hbm_frac_alone': round(lbpp * w * h / alone_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None,
+            'kernel_launches_in_timed_region': launches_total, 'valu': valu, 'composite': composite,
         }
     # whole-pipeline roofline at the Python-wrapper stage boundaries (SURVEY.md 8(d): 41 B/px f16, 79 B/px f32; RCD only: 4*s B/px)
     pipe_bpp = (41 if storage == 'f16' else 79) if args.workload == 'isp' else 4 * sbytes

@@ -35,6 +35,13 @@ for size in [(120, 161), (4, 4), (7, 9), (16, 16), (33, 70), (256, 200), (301, 5
         d = np.abs(got - ref)
         out['laplacian'].append({'size': size, 'prm': prm, 'max': float(d.max()), 'max_in_half_ulps': float((d / half_ulp(np.maximum(np.abs(got), np.abs(ref)))).max()),
                                  'frac_differing': float((d > 0).mean())})
+# 12 MP frame, 11 levels
+lum12 = td.compute_luminance(synthetic_rgb(3072, 4096, seed=99, device=dev))
+prm12 = (0.2, 1.6, 0.7, 0.3)
+got12 = npy(td.Laplacian(dev, (4096, 3072), td.LaplacianParams(6, *prm12)).process(lum12))
+ref12 = O.laplacian(npy(lum12), *prm12)
+d12 = np.abs(got12 - ref12)
+out['laplacian_12mp'] = {'max': float(d12.max()), 'max_in_half_ulps': float((d12 / half_ulp(np.maximum(np.abs(got12), np.abs(ref12)))).max()), 'frac_differing': float((d12 > 0).mean())}
 for size in [(97, 131), (192, 256), (64, 64), (300, 420)]:
     h, w = size
     img = scene(h, w, 77)

@@ -32,6 +32,8 @@ KERNELS = {
     # tile kernel: every lane streams its own image row (16 B per load, 64 different rows per wave request) -> the
     # requests are line-sized, not wide; the finish kernels read slabs and image as coalesced 16-B / 8-B streams
     'wiener_stream': ('tdk_wiener(tiles)', False),
+    # y-streaming tile kernel (K = 32, ov = 4): 16-B staging loads of in-frame groups, 64 consecutive bytes per 4 lanes
+    'wiener_ystream': ('tdk_wiener(tiles)', True),
     'wiener_finish_modify': ('tdk_wiener(finish+modify)', True),
     'wiener_finish<': ('tdk_wiener(finish)', True),
     'rcd_interior': ('tdk_rcd', False),
@@ -65,8 +67,8 @@ def mean_counters(directory):
     return {c: {k: sum(v) / len(v) for k, v in per.items()} for c, per in acc.items()}
 
 
-def static_trans_share():
-    """{kernel fragment: transcendental share of its static VALU instructions}, via profiles/isa_mix.py."""
+def static_trans_share(key='trans'):
+    """{kernel fragment: share of its static VALU instructions that are transcendental (or `key`)}, via profiles/isa_mix.py."""
     try:
         out = subprocess.run([sys.executable, str(Path(__file__).with_name('isa_mix.py')), '--json'], capture_output=True, text=True, timeout=300)
         mix = json.loads(out.stdout)
@@ -78,7 +80,7 @@ def static_trans_share():
         for name, m in mix.items():
             if frag in name:
                 v += m['valu']
-                t += m['trans']
+                t += m.get(key, 0)
         if v:
             share[frag] = t / v
     return share
@@ -111,8 +113,10 @@ def main():
         trans_named = {KERNELS[k][0]: int(v) for k, v in measured_trans.items()}
     else:
         trans_named = {KERNELS[k][0]: int(v * share[k]) for k, v in valu.items() if k in share}
+    pshare = static_trans_share('packed')   # packed fp32 (two operations per lane, 4 SIMD cycles): static share x SQ_INSTS_VALU
+    packed_named = {KERNELS[k][0]: int(v * pshare[k]) for k, v in valu.items() if pshare.get(k)}
     sq_named = {c: {KERNELS[k][0]: round(v, 1) for k, v in per.items()} for c, per in sq.items()}
-    json.dump({**result, '_valu': valu_named, '_trans': trans_named, '_sq': sq_named, '_detail': detail, '_git': git,
+    json.dump({**result, '_valu': valu_named, '_trans': trans_named, '_packed': packed_named, '_sq': sq_named, '_detail': detail, '_git': git,
                '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'}, open(out, 'w'), indent=1)
     print(json.dumps(result, indent=1))
 

@@ -50,7 +50,7 @@ def main():
                 m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
                 if m:
                     cur = m.group(1)
-                    mix[cur] = {'valu': 0, 'trans': 0, 'dpp': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'mfma': 0, 'half': 0, 'cnd_vcc': 0, 'div_fmas': 0}
+                    mix[cur] = {'valu': 0, 'trans': 0, 'packed': 0, 'dpp': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'mfma': 0, 'half': 0, 'cnd_vcc': 0, 'div_fmas': 0}
                     continue
                 if cur is None:
                     continue
@@ -65,6 +65,8 @@ def main():
                     d['valu'] += 1
                     if TRANS.match(op):
                         d['trans'] += 1
+                    elif op.startswith(('v_pk_fma_f32', 'v_pk_add_f32', 'v_pk_mul_f32')):
+                        d['packed'] += 1  # two fp32 operations per lane: 4 SIMD cycles (tests/hip_unit/pk_issue_bench.hip)
                     elif op.startswith('v_cndmask_b32_e32') or op.startswith('v_cndmask_b32_dpp'):
                         d['cnd_vcc'] += 1  # VOP2 select reading VCC: ~23 cycles
                     elif op.startswith('v_div_fmas'):
@@ -87,9 +89,9 @@ def main():
         print(json.dumps(mix))
         return
     for k, v in sorted(mix.items(), key=lambda kv: -kv[1]['valu']):
-        full = v['valu'] - v['trans'] - v['half'] - v['cnd_vcc'] - v['div_fmas']
-        est = full * 2.4 + v['half'] * 4.8 + v['trans'] * 8.5 + (v['cnd_vcc'] + v['div_fmas']) * 23
-        print(f"{v['valu']:6d} valu ({v['trans']:4d} trans, {v['half']:4d} half-rate, {v['cnd_vcc'] + v['div_fmas']:3d} vcc-read, {v['dpp']:3d} xlane) ~{est:8.0f} issue cyc "
+        full = v['valu'] - v['trans'] - v['packed'] - v['half'] - v['cnd_vcc'] - v['div_fmas']
+        est = full * 2.4 + (v['half'] + v['packed']) * 4.8 + v['trans'] * 8.5 + (v['cnd_vcc'] + v['div_fmas']) * 23
+        print(f"{v['valu']:6d} valu ({v['trans']:4d} trans, {v['packed']:4d} packed, {v['half']:4d} half-rate, {v['cnd_vcc'] + v['div_fmas']:3d} vcc-read, {v['dpp']:3d} xlane) ~{est:8.0f} issue cyc "
               f"{v['salu']:5d} salu {v['lds']:5d} lds {v['vmem']:4d} vmem  {k[:110]}")
 
 

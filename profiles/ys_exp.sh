@@ -1,5 +1,6 @@
 set -o pipefail
-timeout -k 10 400 python -m pytest tests -m gpu -x -q -k "wiener or Wiener or fusion or image_processor or process_image_set" > gpurun_out/ys3_tests.log 2>&1
-echo "tests rc=$?" >> gpurun_out/ys3_tests.log
-tail -4 gpurun_out/ys3_tests.log
-python profiles/wiener_ablate_exp.py variants/ys_full.so variants/ys_timing.so > gpurun_out/ys_timing8.txt 2>&1; cat gpurun_out/ys_timing8.txt
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3_gpu_tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/r3_gpu_tests.log
+tail -4 gpurun_out/r3_gpu_tests.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 > gpurun_out/r3_bench_a.json 2> gpurun_out/r3_bench_a.err; tail -c 1500 gpurun_out/r3_bench_a.json
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > gpurun_out/r3_bench_a_s1.json 2> gpurun_out/r3_bench_a_s1.err

@@ -61,8 +61,9 @@ constexpr int NT = 1024;
 //   * every denominator is eps + a sum of non-negative terms (or >= 2e-10 for the direction statistics) and is
 //     bounded by small multiples of M or M^2: 2^-33 < b < 2^44;
 //   * the numerators of steps 1.2 / 4.2 are >= 1e-10; those of step 3.1 are products of non-negative factors
-//     that are 0 or >= m^2 / 2 (cfa * 2 lpf) and, one level up, 0 or >= eps * 2^-68 = 2^-85 -- never -0, never
-//     below 2^-102;
+//     that are 0 or >= m^2 / 2 (cfa * 2 lpf) and, one level up, 0 or >= eps * 2^-68 = 2^-85 with step 3.1's eps = 1e-5
+//     (a gradient >= eps times an estimate >= m * m / (3 * 2^19): a 2^-24 sample between 2^16 neighbours; the case
+//     `tiny_beside_huge` of tests/test_gpu_parity.py builds it) -- never -0, never below 2^-102;
 //   * the numerators of steps 5.1 / 5.2 are signed sums of products of differences and can cancel to anything:
 //     div_signed() checks them per wave (|a| >= 2^-80, which also excludes +-0) and falls back to `/`.
 // Tiles that fail the range check (denormal / huge / NaN samples), border tiles (their stale p/q slots alias

@@ -835,15 +835,18 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
   float* slabs = reinterpret_cast<float*>(workspace);
   float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
   int rc;
-  bool fused_lum = false;
 #ifdef TDK_EXPERIMENTS
+  bool fused_lum = false;
   // log-lightness extracted inside the tile kernel: measured SLOWER than the streaming extraction kernel + plane (the
   // conversion's ~9 transcendentals per pixel cost the issue-bound tile kernel 53 us; the HBM-bound extraction kernel 22 us)
   fused_lum = ysk && getenv("TDK_WIENER_FUSED_LUM") != nullptr;
 #endif
+#ifdef TDK_EXPERIMENTS
   if (fused_lum) {
     rc = launch_tiles_ys_lum<T>(reinterpret_cast<const T*>(rgb_in), slabs, W, H, sigma, eps, g, st_);
-  } else {
+  } else
+#endif
+  {
     rc = tdk_compute_luminance(rgb_in, plane, (int64_t)W * H, 1, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(st_));
     if (rc != TDK_OK) return rc;
     rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
