@@ -440,9 +440,14 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
       ba += __shfl_xor(ba, 32, 64); bb_ += __shfl_xor(bb_, 32, 64);
       if (xr == 0) *reinterpret_cast<float2*>(sm.meta[bb & 7] + 2 * xc) = make_float2(ba, bb_);
       v2f z[K];
-      const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
+      if (__builtin_amdgcn_ballot_w64(!(xa && xb)) == 0) {  // every tile of the strip exists (all strips but the last one)
 #pragma unroll
-      for (int k = 0; k < K; k++) z[k] = v2f{(w[k] * fa) * WindowK<32>::w[k], (w[k + S] * fb) * WindowK<32>::w[k]};
+        for (int k = 0; k < K; k++) z[k] = v2f{w[k] * WindowK<32>::w[k], w[k + S] * WindowK<32>::w[k]};
+      } else {
+        const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; k++) z[k] = v2f{(w[k] * fa) * WindowK<32>::w[k], (w[k + S] * fb) * WindowK<32>::w[k]};
+      }
       fft_inreg_pk<32, false>(z);
       float* dst = sm.fwd[bb & 1] + lane * PITCH;
 #pragma unroll
