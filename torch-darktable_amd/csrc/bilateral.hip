@@ -270,7 +270,15 @@ __global__ __launch_bounds__(256) void slice_modify_kernel(const float* __restri
 // (raster-order gather, x then y then z), so the result is bit-identical to the four-kernel path.
 // Requires that no pixel is clamped onto the last grid column/row (host-checked): then a cell only
 // collects pixels within sigma_s of it and the tile's pixel halo is bounded.
+//
+// Everything that depends on the tile COLUMN only or on the tile ROW only (the cell / pixel ranges, the sample
+// coordinates x / sigma_s, and for every cell the run of pixels that splat into it with their weights) is computed
+// once per launch by bilateral_axis_tables_kernel into a small table in the workspace; a tile workgroup copies its
+// two records into LDS.  (Rounds 1-2 recomputed them in every workgroup: a serial chain of IEEE divisions,
+// floor / ceil and scalar moves that all 8 waves executed, 18 % of a workgroup's life and 15 % of its instructions.)
 constexpr int FTW = 64, FTH = 32, FNT = 512;
+constexpr int TAB_HDR = 4;  // words: c_lo, nc, nmax, 1 spare
+constexpr int TAB_W = 8;    // weights kept per cell: the pixels with a positive weight on a cell span < 2 sigma_s <= 8 (sigma_s <= 4)
 
 struct AxisTile {
   int c_lo;  // first cell kept in LDS (2 below the first cell sliced; may be negative = outside the grid)
@@ -300,9 +308,74 @@ struct TileLds {
   int rs;      // LDS grid row stride in cells (odd: a wave walking rows or columns never bank-conflicts)
   int plane;   // floats per z-slice of the LDS grid (>= rs * max nc_y, multiple of 64: bank == column)
   int usize;   // floats in the sample-tile / blur-temp union
-  int lw, lh;  // max pixels per axis in the sample tile
+  int lw, lh;  // pixels per axis of the sample window of a tile (lw a multiple of 4): the LDS sample tile is lh rows of lw
   int ncx, ncy;  // max cells per axis
+  int hx, hy;  // the sample window of the tile at (x0, y0) starts at max(0, x0 - hx), max(0, y0 - hy); hx a multiple of 4
+  // launch constants the tile kernel would otherwise compute with IEEE divisions in every wave
+  float inv_lw, inv_qw, inv_rs, inv_ncy;  // 1 / lw, 1 / (lw / 4), 1 / rs, 1 / ncy (for fast_div)
+  float rc_r, contrib, norm;              // 1 / sigma_r, 1 / sigma_s^2, -detail * sigma_r * 4
 };
+
+// first pixel and pixel count of a tile's sample window along one axis
+__host__ __device__ inline int win_lo(int p0, int halo) { return p0 > halo ? p0 - halo : 0; }
+__host__ __device__ inline int win_np(int lo, int lp, int size_px) { return lo + lp < size_px ? lp : size_px - lo; }
+
+// words of one axis record: header, sample coordinates of the lp pixels, then per cell the first pixel of its run
+// (relative to the window start; -1: cell outside the grid), then TAB_W weights per cell, k-major
+__host__ __device__ inline int tab_rec(int lp, int nc) { return TAB_HDR + lp + nc * (1 + TAB_W); }
+
+// One 64-thread workgroup per tile column, then per tile row.  For a cell, the pixels with a positive weight
+// (axis_weight above) are consecutive; the record keeps the first one and nmax weights, nmax = the longest run of
+// the record, shorter runs padded with zero weights (a zero weight adds +0 to a non-negative sum: no bit changes)
+// and shifted down where the padding would leave the pixel window.
+__global__ __launch_bounds__(64) void bilateral_axis_tables_kernel(int* __restrict__ tab, int width, int height, GridDims d, float sigma_s, int tiles_x,
+                                                                  TileLds L) {
+  __shared__ int s_nmax;
+  const bool is_x = (int)blockIdx.x < tiles_x;
+  const int ti = is_x ? (int)blockIdx.x : (int)blockIdx.x - tiles_x;
+  const int size_px = is_x ? width : height, size_cells = is_x ? d.sx : d.sy, tile = is_x ? FTW : FTH;
+  const int lp = is_x ? L.lw : L.lh, ncm = is_x ? L.ncx : L.ncy, halo = is_x ? L.hx : L.hy;
+  int* rec = tab + (is_x ? ti * tab_rec(L.lw, L.ncx) : tiles_x * tab_rec(L.lw, L.ncx) + ti * tab_rec(L.lh, L.ncy));
+  const AxisTile t = axis_tile(ti * tile, tile, size_px, size_cells, sigma_s);
+  const int p_lo = win_lo(ti * tile, halo), np = win_np(p_lo, lp, size_px);  // contains [t.p_lo, t.p_lo + t.np) (plan_tiles)
+  float* gs = reinterpret_cast<float*>(rec + TAB_HDR);
+  int* start = rec + TAB_HDR + lp;
+  float* wt = reinterpret_cast<float*>(start + ncm);
+  const int lane = threadIdx.x;
+  if (lane == 0) s_nmax = 1;
+  __syncthreads();
+  for (int i = lane; i < np; i += 64) gs[i] = clampf((float)(p_lo + i) / sigma_s, 0.0f, (float)(size_cells - 1));  // make_sample's gx / gy
+  for (int l = lane; l < t.nc; l += 64) {
+    const int cell = t.c_lo + l;
+    int first = -1;
+    if (cell >= 0 && cell < size_cells) {
+      const int a = max(p_lo, (int)floorf(sigma_s * (float)(cell - 1)) - 1);
+      const int b = min(p_lo + np - 1, (int)ceilf(sigma_s * (float)(cell + 1)) + 1);
+      int k0 = -1, k1 = -1;
+      for (int p = a; p <= b; p++)
+        if (axis_weight(p, sigma_s, size_cells, cell) > 0.0f) { if (k0 < 0) k0 = p; k1 = p; }
+      first = k0 < 0 ? a : k0;
+      if (k0 >= 0) atomicMax(&s_nmax, k1 - k0 + 1);
+    }
+    start[l] = first;
+  }
+  __syncthreads();
+  const int nmax = min(s_nmax, min(TAB_W, np));
+  for (int l = lane; l < t.nc; l += 64) {
+    const int cell = t.c_lo + l;
+    int first = start[l];
+    if (first >= 0) {
+      first = min(first, p_lo + np - nmax);
+      start[l] = first - p_lo;
+    }
+    for (int k = 0; k < TAB_W; k++) {
+      float w = 0.0f;
+      if (first >= 0 && k < nmax) w = fmaxf(axis_weight(first + k, sigma_s, size_cells, cell), 0.0f);
+      wt[k * ncm + l] = w;  // k-major: the lanes of a wave (consecutive cells) read consecutive words
+    }
+  }
+  if (lane == 0) { rec[0] = t.c_lo; rec[1] = t.nc; rec[2] = nmax; }
+}
 
 // x / c for a divisor c that is constant over the launch, rc = 1.0f / c (correctly rounded, host):
 // q = RN(x * rc), r = x - q * c exactly (fma), q' = RN(q + r * rc) is the correctly rounded
@@ -322,23 +395,82 @@ __device__ __forceinline__ float div_by(float x, float c, float rc) {
 // from an integer, far more than the float rounding error, so the truncation is exact.
 __device__ __forceinline__ int fast_div(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The NX candidate pixels per row of one cell column, nmy rows: raster order, each pixel adds its two z
+// contributions to the column (read both cells, then write both: one LDS round trip per pixel).
+template <int NX>
+__device__ __forceinline__ void splat_column(float* __restrict__ acc, const float* __restrict__ urow, const float* __restrict__ wxp, int wxs_stride,
+                                             const float* __restrict__ wyp, int wys_stride, int nmy, int LWS, int PS, int sz, float contrib) {
+  float wxs[NX];
+#pragma unroll
+  for (int k = 0; k < NX; k++) wxs[k] = wxp[k * wxs_stride];
+  for (int j = 0; j < nmy; j++, urow += LWS) {
+    const float wy = wyp[j * wys_stride];
+    float gzv[NX];
+#pragma unroll
+    for (int k = 0; k < NX; k++) gzv[k] = urow[k];
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const float wxy = wxs[k] * wy;
+      const float gz = gzv[k];
+      const int iz = min((int)gz, sz - 2);
+      const float fz = gz - (float)iz;
+      float* p0 = acc + iz * PS;
+      const float a0 = p0[0], a1 = p0[PS];
+      p0[0] = a0 + wxy * (1.0f - fz) * contrib;
+      p0[PS] = a1 + wxy * fz * contrib;
+    }
+  }
+}
+
+// gz = clamp(L / sigma_r, 0, ztop) of N samples: the exact-quotient shortcut of div_by with ONE range test for all N
+template <int N>
+__device__ __forceinline__ void sample_gz(const float (&v)[N], float (&g)[N], float sigma_r, float rc_r, float ztop) {
+  float hi = fabsf(v[0]);
+  float lo = (v[0] == 0.0f) ? 1.0f : hi;  // zeros are safe: take them out of the lower bound
+#pragma unroll
+  for (int k = 1; k < N; k++) {
+    const float a = fabsf(v[k]);
+    hi = fmaxf(hi, a);  // (a NaN sample fails the test below through lo or hi: fmaxf / fminf drop it, so test it separately)
+    lo = fminf(lo, (v[k] == 0.0f) ? 1.0f : a);
+  }
+  bool safe = lo >= 0x1p-40f && hi <= 0x1p40f && sigma_r >= 0x1p-20f && sigma_r <= 0x1p20f;
+#pragma unroll
+  for (int k = 0; k < N; k++) safe = safe && (v[k] == v[k]);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!safe) != 0, 0)) {
+#pragma unroll
+    for (int k = 0; k < N; k++) g[k] = clampf(v[k] / sigma_r, 0.0f, ztop);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float q = v[k] * rc_r;
+    const float r = __builtin_fmaf(-q, sigma_r, v[k]);
+    g[k] = clampf(__builtin_fmaf(r, rc_r, q), 0.0f, ztop);
+  }
+}
+
 // MODE 0: luminance plane in (TL == T) -> filtered plane out; 1 / 2: fp32 plane + RGB in -> RGB out (linear / log)
-template <typename TL, typename T, int MODE, int VEC, int MAXC>
-__global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restrict__ lum, const T* __restrict__ rgb, T* __restrict__ out, int width,
-                                                            int height, GridDims d, float sigma_s, float sigma_r, float detail, int tiles_x,
-                                                            int ntiles, TileLds L) {
+template <typename TL, typename T, int MODE, int VEC>
+__global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(8, 8))) void bilateral_tile_kernel(
+    const TL* __restrict__ lum, const T* __restrict__ rgb, T* __restrict__ out, const int* __restrict__ tab, int width, int height, GridDims d,
+    float sigma_r, int tiles_x, int ntiles, TileLds L) {
   extern __shared__ float smem[];
 #ifdef TDK_BIL_TIMING
   unsigned long long bil_t0 = clock64();
 #endif
   float* A = smem;                      // [sz][plane] grid, cell (lx, ly) at ly * RS + lx
-  float* U = A + d.sz * L.plane;        // z sample coordinate of every pixel of the tile + halo, then blur temp
-  float* gxs = U + L.usize;             // x sample coordinate of pixel column p_lo + i
+  float* U = A + d.sz * L.plane;        // z sample coordinate of every pixel of the sample window (lh rows of lw), then blur temp
+  float* gxs = U + L.usize;             // x sample coordinate of pixel column px_lo + i
   float* gys = gxs + L.lw;
-  float* WX = U + L.lw * L.lh;          // (tail of U, dead before the blur) [nc_x][MAXC] splat weight of candidate pixel k on cell column lx (-1: none)
-  float* WY = WX + L.ncx * MAXC;
-  int* xa_t = reinterpret_cast<int*>(WY + L.ncy * MAXC);  // first candidate pixel (tile-relative) of a cell column; -1: outside the grid
-  int* ya_t = xa_t + L.ncx;
+  int* TX = reinterpret_cast<int*>(U + L.lw * L.lh);  // (tail of U, dead before the blur) x record: start[ncx] then weights[ncx][TAB_W]
+  int* TY = TX + L.ncx * (1 + TAB_W);
 
   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles
   const int chunk = gridDim.x >> 3;
@@ -346,156 +478,194 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
   if (tile >= ntiles) return;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int x0 = txi * FTW, y0 = tyi * FTH;
-  const AxisTile ax = axis_tile(x0, FTW, width, d.sx, sigma_s), ay = axis_tile(y0, FTH, height, d.sy, sigma_s);
+  const int recx = tab_rec(L.lw, L.ncx), recy = tab_rec(L.lh, L.ncy);
+  const int* rx = tab + txi * recx;
+  const int* ry = tab + tiles_x * recx + tyi * recy;
+  const int px_lo = win_lo(x0, L.hx), py_lo = win_lo(y0, L.hy);
+  const int npx = win_np(px_lo, L.lw, width), npy = win_np(py_lo, L.lh, height);
   const int tid = threadIdx.x;
-  const int PS = L.plane, RS = L.rs, LWS = ax.np;
-  const float ztop = (float)(d.sz - 1), rc_r = 1.0f / sigma_r;
+  const int PS = L.plane, RS = L.rs, LWS = L.lw;
+  const float ztop = (float)(d.sz - 1), rc_r = L.rc_r;
 
-  const float rc_s = 1.0f / sigma_s;
-  for (int i = tid; i < ax.np; i += FNT) gxs[i] = clampf(div_by((float)(ax.p_lo + i), sigma_s, rc_s), 0.0f, (float)(d.sx - 1));
-  for (int i = tid; i < ay.np; i += FNT) gys[i] = clampf(div_by((float)(ay.p_lo + i), sigma_s, rc_s), 0.0f, (float)(d.sy - 1));
-  // per-axis splat tables: a pixel with sample coordinate g (base cell ib, fraction f) gives cell ib
-  // the weight 1 - f and cell ib + 1 the weight f (axis_weight above)
-  auto axis_tables = [&](const AxisTile& t, int size_px, int size_cells, float* W, int* first) {
-    for (int i = tid; i < t.nc * MAXC; i += FNT) {
-      const int l = i / MAXC, k = i - l * MAXC, cell = t.c_lo + l;
-      float w = -1.0f;
-      int a = -1;
-      if (cell >= 0 && cell < size_cells) {
-        a = max(t.p_lo, (int)floorf(sigma_s * (float)(cell - 1)) - 1);
-        const int b = min(t.p_lo + t.np - 1, (int)ceilf(sigma_s * (float)(cell + 1)) + 1);
-        if (a + k <= b) w = axis_weight(a + k, sigma_s, size_cells, cell);
-        a -= t.p_lo;
-      }
-      W[i] = w;
-      if (k == 0) first[l] = a;
-    }
-  };
-  BIL_MARK(6);
-  axis_tables(ax, width, d.sx, WX, xa_t);
-  axis_tables(ay, height, d.sy, WY, ya_t);
-  BIL_MARK(7);
+  // ---- set-up: the tile's luminance samples and its two table records into LDS.  All global loads are issued before
+  // the first one is waited for; their addresses need nothing but the kernel arguments.
   {
-    const float inv_np = 1.0f / (float)ax.np;
-    const TL* src = lum + (size_t)ay.p_lo * width + ax.p_lo;
-    // all loads of a thread first, then the arithmetic: a loop of load -> use pays the global latency once per iteration
-    // (measured: this phase was 30 % of the workgroup's time with one exposed latency per sample)
-    constexpr int BATCH = 6;
-    const int total = ax.np * ay.np;
-    for (int base = tid; base < total; base += BATCH * FNT) {
-      float v[BATCH];
+    // each record part is at most 2 * FNT words (plan_tiles): two guarded copies, no loop
+    auto copy2 = [&](int* dst, const int* from, int n) {
+      if (tid < n) dst[tid] = from[tid];
+      if (tid + FNT < n) dst[tid + FNT] = from[tid + FNT];
+    };
+    auto copy_records = [&]() {
+      copy2(reinterpret_cast<int*>(gxs), rx + TAB_HDR, L.lw);
+      copy2(reinterpret_cast<int*>(gys), ry + TAB_HDR, L.lh);
+      copy2(TX, rx + TAB_HDR + L.lw, L.ncx * (1 + TAB_W));
+      copy2(TY, ry + TAB_HDR + L.lh, L.ncy * (1 + TAB_W));
+    };
+    const TL* src = lum + (size_t)py_lo * width + px_lo;
+    if constexpr (VEC == 4) {
+      // 4 samples per load: the window starts on a multiple of 4 pixels, the rows are 16-B aligned (host-checked)
+      const int qw = L.lw >> 2, total = qw * npy;
+      constexpr int NB = 2;
+      for (int base = tid; base - tid < total; base += NB * FNT) {  // uniform trip count: every thread helps copy the records
+        float v[NB][4];
+        int at[NB];
 #pragma unroll
-      for (int k = 0; k < BATCH; k++) {
-        const int i = base + k * FNT;
-        const int r = fast_div(i, inv_np), c = i - r * ax.np;
-        v[k] = (i < total) ? ld(src, (size_t)(r * width + c)) : 0.0f;
+        for (int k = 0; k < NB; k++) {
+          const int q = base + k * FNT;
+          const int r = fast_div(q, L.inv_qw), c = (q - r * qw) * 4;
+          at[k] = (q < total && c < npx) ? r * LWS + c : -1;
+          if (at[k] >= 0) s4_io<TL>::load(src + (size_t)r * width + c, 0, v[k]);
+        }
+        if (base == tid) copy_records();  // the records ride behind the first batch of samples
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          if (at[k] >= 0) {
+            float g[4];
+            sample_gz<4>(v[k], g, sigma_r, rc_r, ztop);  // make_sample's gz
+            *reinterpret_cast<float4*>(U + at[k]) = make_float4(g[0], g[1], g[2], g[3]);
+          }
+        }
       }
+    } else {
+      const int total = LWS * npy;
+      constexpr int NB = 7;
+      for (int base = tid; base - tid < total; base += NB * FNT) {  // uniform trip count: every thread helps copy the records
+        float v[NB];
+        bool on[NB];
 #pragma unroll
-      for (int k = 0; k < BATCH; k++) {
-        const int i = base + k * FNT;
-        if (i < total) U[i] = clampf(div_by(v[k], sigma_r, rc_r), 0.0f, ztop);  // make_sample's gz
+        for (int k = 0; k < NB; k++) {
+          const int i = base + k * FNT;
+          const int r = fast_div(i, L.inv_lw), c = i - r * LWS;
+          on[k] = i < total && c < npx;
+          v[k] = on[k] ? ld(src, (size_t)r * width + c) : 0.0f;
+        }
+        if (base == tid) copy_records();
+        float g[NB];
+        sample_gz<NB>(v, g, sigma_r, rc_r, ztop);
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+          if (on[k]) U[base + k * FNT] = g[k];
       }
     }
   }
+  AxisTile ax, ay;  // only the cell ranges; the pixel windows are px_lo / npx, py_lo / npy
+  ax.c_lo = rx[0]; ax.nc = rx[1]; ay.c_lo = ry[0]; ay.nc = ry[1];
+  const int nmx = rx[2], nmy = ry[2];
   BIL_MARK(8);
-  for (int i = tid; i < d.sz * PS; i += FNT) A[i] = 0.0f;
-  BIL_MARK(9);
-  __syncthreads();
+  lds_barrier();
   BIL_MARK(0);
 
-  // ---- splat (gather, raster order per column; same expressions as splat_gather_kernel)
-  const float contrib = 1.0f / (sigma_s * sigma_s);
+  // ---- splat (gather, raster order per column; same expressions as splat_gather_kernel).  A thread owns the sz cells of
+  // its column: it clears them and accumulates in place.
+  const float contrib = L.contrib;
   {
-    const int ncol = ax.nc * ay.nc;
-    const float inv_nc = 1.0f / (float)ax.nc;
+    const int ncol = RS * ay.nc;
+    const float* WX = reinterpret_cast<const float*>(TX + L.ncx);
+    const float* WY = reinterpret_cast<const float*>(TY + L.ncy);
     for (int c = tid; c < ncol; c += FNT) {
-      const int ly = fast_div(c, inv_nc), lx = c - ly * ax.nc;
-      const int xa = xa_t[lx], ya = ya_t[ly];
+      const int ly = fast_div(c, L.inv_rs), lx = c - ly * RS;
+      if (lx >= ax.nc) continue;  // padding column of the odd row stride
+      const int xa = TX[lx], ya = TY[ly];
+      float* acc = A + c;
+      for (int z = 0; z < d.sz; z++) acc[z * PS] = 0.0f;
       if (xa < 0 || ya < 0) continue;  // cell outside the grid: stays zero
-      float* acc = A + ly * RS + lx;
-      float wxs[MAXC];
-#pragma unroll
-      for (int k = 0; k < MAXC; k++) wxs[k] = WX[lx * MAXC + k];
       const float* urow = U + ya * LWS + xa;
-      for (int j = 0; j < MAXC; j++, urow += LWS) {
-        const float wy = WY[ly * MAXC + j];
-        if (!(wy > 0.0f)) continue;
+      const float* wxp = WX + lx;
+      const float* wyp = WY + ly;
+      switch (nmx) {
+        case 1: splat_column<1>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 2: splat_column<2>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 3: splat_column<3>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 4: splat_column<4>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 5: splat_column<5>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 6: splat_column<6>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        case 7: splat_column<7>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+        default: splat_column<8>(acc, urow, wxp, L.ncx, wyp, L.ncy, nmy, LWS, PS, d.sz, contrib); break;
+      }
+    }
+  }
+  lds_barrier();
+  BIL_MARK(1);
+
+  // ---- blur x: A -> U, one thread per (z, row) with a register window, CH cells per step: the reads of a step are
+  // independent and issued together (a cell-by-cell walk pays one LDS latency per cell: it was 20 % of the workgroup's
+  // life).  Cells beyond the LDS tile read as zero; they only feed cells nobody slices.
+  const float w0 = 6.0f / 16.0f, w1 = 4.0f / 16.0f, w2 = 1.0f / 16.0f;
+  {
+    constexpr int CH = 13;
+    for (int row = tid; row < d.sz * L.ncy; row += FNT) {
+      const int z = fast_div(row, L.inv_ncy), ly = row - z * L.ncy;
+      if (ly >= ay.nc) continue;
+      const float* p = A + z * PS + ly * RS;
+      float* q = U + z * PS + ly * RS;
+      float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[1];  // nc >= 6
+      for (int lx0 = 0; lx0 < ax.nc; lx0 += CH) {
+        float nx[CH];
 #pragma unroll
-        for (int k = 0; k < MAXC; k++) {
-          if (wxs[k] > 0.0f) {
-            const float wxy = wxs[k] * wy;
-            const float gz = urow[k];
-            const int iz = min((int)gz, d.sz - 2);
-            const float fz = gz - (float)iz;
-            acc[iz * PS] += wxy * (1.0f - fz) * contrib;
-            acc[(iz + 1) * PS] += wxy * fz * contrib;
-          }
+        for (int k = 0; k < CH; k++) nx[k] = (lx0 + k + 2 < ax.nc) ? p[lx0 + k + 2] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          if (lx0 + k < ax.nc) q[lx0 + k] = c0 * w0 + w1 * (p1 + m1) + w2 * (nx[k] + m2);
+          m2 = m1; m1 = c0; c0 = p1; p1 = nx[k];
         }
       }
     }
   }
-  __syncthreads();
-  BIL_MARK(1);
-
-  // ---- blur x: A -> U, one thread per (z, row) with a register window (cells beyond the LDS tile
-  // read as zero; they only feed cells nobody slices).  (Cutting the rows into segments for more threads, or
-  // prefetching four cells, did not shorten this phase: its LDS reads queue behind the other workgroups' splats.)
-  const float w0 = 6.0f / 16.0f, w1 = 4.0f / 16.0f, w2 = 1.0f / 16.0f;
-  {
-    const float inv_ncy = 1.0f / (float)ay.nc;
-    for (int row = tid; row < d.sz * ay.nc; row += FNT) {
-      const int z = fast_div(row, inv_ncy), ly = row - z * ay.nc;
-      const float* p = A + z * PS + ly * RS;
-      float* q = U + z * PS + ly * RS;
-      float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[1];  // nc >= 6
-      for (int lx = 0; lx < ax.nc; lx++) {
-        const float p2 = (lx + 2 < ax.nc) ? p[lx + 2] : 0.0f;
-        q[lx] = c0 * w0 + w1 * (p1 + m1) + w2 * (p2 + m2);
-        m2 = m1; m1 = c0; c0 = p1; p1 = p2;
-      }
-    }
-  }
-  __syncthreads();
+  lds_barrier();
   BIL_MARK(2);
-  // ---- blur y: U -> A, one thread per (z, column), four reads in flight (the column walk strides over whole rows)
+  // ---- blur y: U -> A, one thread per (z, column)
   {
-    const float inv_ncx = 1.0f / (float)ax.nc;
-    for (int cc = tid; cc < d.sz * ax.nc; cc += FNT) {
-      const int z = fast_div(cc, inv_ncx), lx = cc - z * ax.nc;
+    constexpr int CH = 11;
+    for (int cc = tid; cc < d.sz * RS; cc += FNT) {
+      const int z = fast_div(cc, L.inv_rs), lx = cc - z * RS;
+      if (lx >= ax.nc) continue;
       const float* p = U + z * PS + lx;
       float* q = A + z * PS + lx;
       float m2 = 0.0f, m1 = 0.0f, c0 = p[0], p1 = p[RS];
-      for (int ly0 = 0; ly0 < ay.nc; ly0 += 4) {
-        float nx[4];
+      for (int ly0 = 0; ly0 < ay.nc; ly0 += CH) {
+        float nx[CH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) nx[k] = (ly0 + k + 2 < ay.nc) ? p[(ly0 + k + 2) * RS] : 0.0f;
+        for (int k = 0; k < CH; k++) nx[k] = (ly0 + k + 2 < ay.nc) ? p[(ly0 + k + 2) * RS] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < CH; k++) {
           if (ly0 + k < ay.nc) q[(ly0 + k) * RS] = c0 * w0 + w1 * (p1 + m1) + w2 * (nx[k] + m2);
           m2 = m1; m1 = c0; c0 = p1; p1 = nx[k];
         }
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   BIL_MARK(3);
-  // ---- z derivative, in place (register window), one thread per column
-  for (int c = tid; c < RS * ay.nc; c += FNT) {
-    float* p = A + c;
+  // ---- z derivative, in place, one thread per column: the whole column in registers when it is short
+  {
     const float v1 = 4.0f / 16.0f, v2 = 2.0f / 16.0f;
-    float m2 = 0.0f, m1 = 0.0f, c0 = p[0];
-    float p1 = (d.sz > 1) ? p[PS] : 0.0f;
-    for (int z = 0; z < d.sz; z++) {
-      const float p2 = (z + 2 < d.sz) ? p[(z + 2) * PS] : 0.0f;
-      p[z * PS] = v1 * (p1 - m1) + v2 * (p2 - m2);
-      m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+    constexpr int ZR = 8;
+    for (int c = tid; c < RS * ay.nc; c += FNT) {
+      float* p = A + c;
+      if (d.sz <= ZR) {
+        float v[ZR + 4];
+        v[0] = v[1] = 0.0f;
+#pragma unroll
+        for (int z = 0; z < ZR + 2; z++) v[z + 2] = (z < d.sz) ? p[z * PS] : 0.0f;
+#pragma unroll
+        for (int z = 0; z < ZR; z++)
+          if (z < d.sz) p[z * PS] = v1 * (v[z + 3] - v[z + 1]) + v2 * (v[z + 4] - v[z]);
+      } else {
+        float m2 = 0.0f, m1 = 0.0f, c0 = p[0];
+        float p1 = (d.sz > 1) ? p[PS] : 0.0f;
+        for (int z = 0; z < d.sz; z++) {
+          const float p2 = (z + 2 < d.sz) ? p[(z + 2) * PS] : 0.0f;
+          p[z * PS] = v1 * (p1 - m1) + v2 * (p2 - m2);
+          m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+        }
+      }
     }
   }
-  __syncthreads();
+  lds_barrier();
   BIL_MARK(4);
 
   // ---- slice (+ put the new lightness back into the pixel)
-  const float norm = -detail * sigma_r * 4.0f;
+  const float norm = L.norm;
   constexpr int GW = FTW / VEC;
   for (int g = tid; g < GW * FTH; g += FNT) {
     const int py = g / GW, y = y0 + py, x = x0 + (g - py * GW) * VEC;
@@ -509,17 +679,19 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
       Lv[0] = ld(lum, i0);
       if constexpr (MODE != 0) { o[0] = ld(rgb, i0 * 3); o[1] = ld(rgb, i0 * 3 + 1); o[2] = ld(rgb, i0 * 3 + 2); }
     }
-    const float gy = gys[y - ay.p_lo];
+    const float gy = gys[y - py_lo];
     const int iy = min((int)gy, d.sy - 2);
     const float by = gy - (float)iy, ayw = 1.0f - by;
     const float* grow = A + (iy - ay.c_lo) * RS - ax.c_lo;
+    float gzv[VEC];
+    sample_gz<VEC>(Lv, gzv, sigma_r, rc_r, ztop);
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
       const float Lp = Lv[k];
-      const float gx = gxs[x + k - ax.p_lo];
+      const float gx = gxs[x + k - px_lo];
       const int ix = min((int)gx, d.sx - 2);
       const float bx = gx - (float)ix, axw = 1.0f - bx;
-      const float gz = clampf(div_by(Lp, sigma_r, rc_r), 0.0f, ztop);
+      const float gz = gzv[k];
       const int iz = min((int)gz, d.sz - 2);
       const float bz = gz - (float)iz, azw = 1.0f - bz;
       const int oy = RS, oz = PS;
@@ -548,55 +720,85 @@ __global__ __launch_bounds__(FNT) void bilateral_tile_kernel(const TL* __restric
 
 constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;  // two workgroups per CU
 
-// Decide whether the tile kernel applies and size its LDS.  Returns false -> four-kernel path.
-// candidate pixels per axis of one grid column: <= 2 sigma_s + 5, exactly 2 sigma_s + 3 for integer sigma_s
-static int tile_maxc(float sigma_s) {
-  return ((2.0f * sigma_s + 5.0f <= 8.0f) || (sigma_s == floorf(sigma_s) && 2.0f * sigma_s + 3.0f <= 8.0f)) ? 8 : 14;
-}
-
 // test hook (tdk_bilateral_select_path): take the general four-kernel path even where the tile kernel applies
 static std::atomic<int> g_force_general_path{0};
 
-static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, TileLds* L, size_t* lds_bytes) {
-  const int maxc = tile_maxc(sigma_s);  // sigma_s <= 4: 2 * 4 + 5 <= 14
+// Decide whether the tile kernel applies and size its LDS.  Returns false -> four-kernel path.
+// sigma_s <= 4: the pixels with a positive weight on one cell lie within sigma_s of it on either side, at most 7 <= TAB_W.
+static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail, TileLds* L, size_t* lds_bytes) {
   if (g_force_general_path.load(std::memory_order_relaxed)) return false;
   if (!(sigma_s >= 1.0f && sigma_s <= 4.0f)) return false;
   // no pixel may be clamped onto the last column / row (those columns collect far-away pixels)
   if ((float)(width - 1) / sigma_s > (float)(d.sx - 1) || (float)(height - 1) / sigma_s > (float)(d.sy - 1)) return false;
-  int ncx = 0, ncy = 0, lw = 0, lh = 0;
+  // One sample-window shape for all tiles: it starts hx (hy) pixels before the tile and is lw (lh) pixels long, the
+  // smallest values that contain the pixels axis_tile() asks for in every tile column (row); hx and lw in whole
+  // 4-pixel groups so that a window row loads as 16-B groups.
+  int ncx = 0, ncy = 0, hx = 0, hy = 0, lw = 0, lh = 0;
   for (int x0 = 0; x0 < width; x0 += FTW) {
     const AxisTile t = axis_tile(x0, FTW, width, d.sx, sigma_s);
-    ncx = t.nc > ncx ? t.nc : ncx; lw = t.np > lw ? t.np : lw;
+    ncx = t.nc > ncx ? t.nc : ncx; hx = x0 - t.p_lo > hx ? x0 - t.p_lo : hx;
+  }
+  hx = (hx + 3) & ~3;
+  for (int x0 = 0; x0 < width; x0 += FTW) {
+    const AxisTile t = axis_tile(x0, FTW, width, d.sx, sigma_s);
+    const int n = t.p_lo + t.np - win_lo(x0, hx);
+    lw = n > lw ? n : lw;
+  }
+  lw = (lw + 3) & ~3;
+  for (int y0 = 0; y0 < height; y0 += FTH) {
+    const AxisTile t = axis_tile(y0, FTH, height, d.sy, sigma_s);
+    ncy = t.nc > ncy ? t.nc : ncy; hy = y0 - t.p_lo > hy ? y0 - t.p_lo : hy;
   }
   for (int y0 = 0; y0 < height; y0 += FTH) {
     const AxisTile t = axis_tile(y0, FTH, height, d.sy, sigma_s);
-    ncy = t.nc > ncy ? t.nc : ncy; lh = t.np > lh ? t.np : lh;
+    const int n = t.p_lo + t.np - win_lo(y0, hy);
+    lh = n > lh ? n : lh;
   }
   L->rs = ncx | 1;
   L->plane = (int)tdk_align_up((size_t)L->rs * ncy, 64);
-  const int lt = lw * lh + (ncx + ncy) * (maxc + 1), bt = d.sz * L->plane;  // sample tile + splat tables | blur temp
+  const int lt = lw * lh + (ncx + ncy) * (1 + TAB_W), bt = d.sz * L->plane;  // sample tile + the two table records | blur temp
   L->usize = (int)tdk_align_up((size_t)(lt > bt ? lt : bt), 64);
   L->lw = lw; L->lh = lh;
   L->ncx = ncx; L->ncy = ncy;
+  L->hx = hx; L->hy = hy;
+  L->inv_lw = 1.0f / (float)lw; L->inv_qw = 1.0f / (float)(lw / 4); L->inv_rs = 1.0f / (float)L->rs; L->inv_ncy = 1.0f / (float)ncy;
+  L->rc_r = 1.0f / sigma_r; L->contrib = 1.0f / (sigma_s * sigma_s); L->norm = -detail * sigma_r * 4.0f;
   *lds_bytes = ((size_t)d.sz * L->plane + L->usize + (size_t)lw + (size_t)lh) * sizeof(float);
+  if (lw > 2 * FNT || lh > 2 * FNT || ncx * (1 + TAB_W) > 2 * FNT || ncy * (1 + TAB_W) > 2 * FNT) return false;  // record copies of the tile kernel
   return *lds_bytes <= FUSED_LDS_LIMIT;
 }
 
+// bytes of the per-launch axis tables (0 when the tile kernel does not apply); they sit behind everything else in the workspace
+static size_t tile_table_bytes(int width, int height, float sigma_s, float sigma_r) {
+  const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
+  TileLds L;
+  size_t lds_bytes = 0;
+  if (!plan_tiles(width, height, d, sigma_s, sigma_r, 0.0f, &L, &lds_bytes)) return 0;
+  const size_t words = (size_t)tdk_div_up(width, FTW) * tab_rec(L.lw, L.ncx) + (size_t)tdk_div_up(height, FTH) * tab_rec(L.lh, L.ncy);
+  return tdk_align_up(words * sizeof(int), 256);
+}
+
 template <typename TL, typename T, int MODE>
-int launch_tiles(const TL* lum, const T* rgb, T* out, int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail,
+int launch_tiles(const TL* lum, const T* rgb, T* out, int* tab, int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail,
                  const TileLds& L, size_t lds_bytes, bool vec, hipStream_t s) {
-  const int tiles_x = tdk_div_up(width, FTW), ntiles = tiles_x * tdk_div_up(height, FTH);
+  const int tiles_x = tdk_div_up(width, FTW), tiles_y = tdk_div_up(height, FTH), ntiles = tiles_x * tiles_y;
   const dim3 grid(8 * tdk_div_up(ntiles, 8));
-#define TDK_BT(VECV, MAXCV)                                                                                                                       \
+  TDK_LAUNCH("tdk_bilateral(tables)", bilateral_axis_tables_kernel, dim3(tiles_x + tiles_y), dim3(64), 0, s, tab, width, height, d, sigma_s, tiles_x, L);
+#define TDK_BT(VECV)                                                                                                                              \
   do {                                                                                                                                            \
-    TDK_MAX_LDS_ONCE((bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), "tdk_bilateral(hipFuncSetAttribute)");                                    \
-    TDK_LAUNCH("tdk_bilateral(tiles)", (bilateral_tile_kernel<TL, T, MODE, VECV, MAXCV>), grid, dim3(FNT), lds_bytes, s, lum, rgb, out, width, height, d, \
-               sigma_s, sigma_r, detail, tiles_x, ntiles, L);                                                                                     \
+    TDK_MAX_LDS_ONCE((bilateral_tile_kernel<TL, T, MODE, VECV>), "tdk_bilateral(hipFuncSetAttribute)");                                           \
+    TDK_LAUNCH("tdk_bilateral(tiles)", (bilateral_tile_kernel<TL, T, MODE, VECV>), grid, dim3(FNT), lds_bytes, s, lum, rgb, out, tab, width, height, d, \
+               sigma_r, tiles_x, ntiles, L);                                                                                                      \
   } while (0)
-  if (tile_maxc(sigma_s) == 8) { if (vec) TDK_BT(4, 8); else TDK_BT(1, 8); }
-  else { if (vec) TDK_BT(4, 14); else TDK_BT(1, 14); }
+  if (vec) TDK_BT(4); else TDK_BT(1);
 #undef TDK_BT
   return TDK_OK;
+}
+
+// workspace layout: grid | tmp | [fp32 luminance plane (rgb entry points)] | axis tables of the tile kernel
+static size_t grid_workspace_bytes(const GridDims& d) { return tdk_align_up(2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) * sizeof(float), 256); }
+static size_t rgb_workspace_bytes(const GridDims& d, int width, int height) {
+  return tdk_align_up((2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) + (size_t)width * height) * sizeof(float), 256);
 }
 
 // splat -> blur x,y -> z derivative; leaves the final grid in `grid`
@@ -630,9 +832,10 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
   const T* in = reinterpret_cast<const T*>(lum_in);
   TileLds L;
   size_t lds_bytes = 0;
-  if (lum_in != lum_out && plan_tiles(width, height, d, sigma_s, &L, &lds_bytes)) {  // tiles read a pixel halo: not in place
+  if (lum_in != lum_out && plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {  // tiles read a pixel halo: not in place
     const bool vec = (width % 4) == 0 && tdk_aligned(lum_in, 16) && tdk_aligned(lum_out, 16);
-    return launch_tiles<T, T, 0>(in, nullptr, reinterpret_cast<T*>(lum_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + grid_workspace_bytes(d));
+    return launch_tiles<T, T, 0>(in, nullptr, reinterpret_cast<T*>(lum_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
   }
   const int rc = build_grid<T>(in, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
@@ -659,9 +862,10 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
   const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
   TileLds L;
   size_t lds_bytes = 0;
-  if (plan_tiles(width, height, d, sigma_s, &L, &lds_bytes)) {
-    if (log_mode) return launch_tiles<float, T, 2>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
-    return launch_tiles<float, T, 1>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+  if (plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + rgb_workspace_bytes(d, width, height));
+    if (log_mode) return launch_tiles<float, T, 2>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+    return launch_tiles<float, T, 1>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
   }
   rc = build_grid<float>(plane, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
@@ -695,7 +899,7 @@ TDK_EXPORT int tdk_bilateral_grid_size(int width, int height, float sigma_s, flo
 TDK_EXPORT size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r) {
   if (width <= 0 || height <= 0 || !(sigma_r > 0.0f)) return 0;
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  return tdk_align_up(2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) * sizeof(float), 256);
+  return grid_workspace_bytes(d) + tile_table_bytes(width, height, sigma_s, sigma_r);
 }
 
 TDK_EXPORT int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
@@ -710,7 +914,7 @@ TDK_EXPORT int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace,
 TDK_EXPORT size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r) {
   if (width <= 0 || height <= 0 || !(sigma_r > 0.0f)) return 0;
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  return tdk_align_up((2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) + (size_t)width * height) * sizeof(float), 256);
+  return rgb_workspace_bytes(d, width, height) + tile_table_bytes(width, height, sigma_s, sigma_r);
 }
 
 TDK_EXPORT int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
