@@ -178,6 +178,43 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
   border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
+// The ring in two passes through LDS (used beside rcd_stream): a workgroup owns a 32 x 7 (top / bottom bands) or 7 x 32 (left /
+// right bands, rows [7, h - 7)) piece of the ring, computes the intermediate image of border_temp() ONCE per position of the
+// piece and its 1-px surround (border_pixel evaluates it nine times per pixel: 25 us of dependent loads at 12 MP), then the
+// red/blue fill from the staged values.  Same expressions as border_pixel.  Needs w > 14 and h > 14.
+constexpr int RING_LEN = 32, RING_NT = 320;  // (32 + 2) x 9 = 306 staged positions: one per thread
+template <typename TI, typename T>
+__global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nbx, int nby) {
+  __shared__ float tmp[3][(RING_LEN + 2) * 9];
+  int b = blockIdx.x, x0, y0, bw, bh;
+  if (b < 2 * nbx) {  // top, then bottom band
+    x0 = (b % nbx) * RING_LEN; y0 = b < nbx ? 0 : h - 7;
+    bw = min(RING_LEN, w - x0); bh = 7;
+  } else {            // left, then right band
+    b -= 2 * nbx;
+    x0 = b < nby ? 0 : w - 7; y0 = 7 + (b % nby) * RING_LEN;
+    bw = 7; bh = min(RING_LEN, h - 7 - y0);
+  }
+  const int tw = bw + 2, th = bh + 2;
+  for (int i = threadIdx.x; i < tw * th; i += RING_NT) {
+    const int ty = i / tw, tx = i - ty * tw;
+    const f3 t = border_temp(in, x0 - 1 + tx, y0 - 1 + ty, w, h, pattern);
+    tmp[0][i] = fmaxf(0.0f, t.x); tmp[1][i] = fmaxf(0.0f, t.y); tmp[2][i] = fmaxf(0.0f, t.z);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bw * bh; i += RING_NT) {
+    const int py = i / bw, px = i - py * bw, x = x0 + px, y = y0 + py;
+    const int c0 = (py + 1) * tw + px + 1;
+    auto nb = [&](int dx, int dy) { const int q = c0 + dy * tw + dx; return mk3(tmp[0][q], tmp[1][q], tmp[2][q]); };
+    f3 col = nb(0, 0);
+    if (y > 0 && x > 0 && x < w - 1 && y < h - 1) col = ppg_redblue(nb, col, cfa_color(y, x, pattern), cfa_color(y, x + 1, pattern) == 0);
+    const size_t p = (size_t)y * w + x;
+    st(out, p * 3, fmaxf(col.x, 0.0f));
+    st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
+    st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
+  }
+}
+
 // One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
 // (all the `row/col >= k && <= size - k` guards of the nine steps hold for every site the tile
 // touches): the guards compile away, which removes ~10 % of the instructions of 93 % of the tiles.
@@ -606,18 +643,39 @@ __device__ __forceinline__ bool load_tile(const TI* __restrict__ in, int w, int 
   }
 }
 
+#include "tdk_rcd_stream.h"
+
 // Persistent workgroups (one per CU: the five planes fill its LDS).  Work list: `nborder` chunks of the border
 // ring (independent of the tiles: disjoint output pixels, input read-only), then the tiles; workgroup b takes
 // tiles b, b + G, b + 2G, ...  The column of a tile is rotated by 7 per tile row so that the slower border-column
 // tiles spread over the workgroups instead of landing on the same two.
 template <typename TI, typename T>   // TI: storage type of the mosaic, T: of the RGB result
 __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int wide_ok, int nborder,
-                                                    int tiles_x, int tiles_y) {
+                                                    int tiles_x, int tiles_y, int border_only) {
   extern __shared__ float lds[];
-  const int G = (int)gridDim.x, ntiles = tiles_x * tiles_y;
+  const int G = (int)gridDim.x;
   for (int i = (int)blockIdx.x; i < nborder; i += G) border_pixel(in, out, w, h, pattern, (int64_t)i * NT + threadIdx.x);
 
+  // border_only (the interior goes to rcd_stream): the work list holds only the tiles that touch a border rule -- the first and
+  // last tile rows completely, the first and last column(s) of the rows in between
+  const int ix0 = 1, ix1 = (w - TW - HALO) / TW, iy0 = 1, iy1 = (h - TH - HALO) / TH;  // interior tiles: [ix0, ix1] x [iy0, iy1]
+  const int ncols_side = tiles_x - (ix1 - ix0 + 1), nmid = iy1 - iy0 + 1;              // border tiles per middle row; middle rows
+  const int ntiles = border_only ? tiles_x * (tiles_y - nmid) + ncols_side * nmid : tiles_x * tiles_y;
   auto locate = [&](int t, int& tx, int& ty) -> bool {  // tile number -> position; true: clear of every image-border rule
+    if (border_only) {
+      const int ntop = tiles_x * iy0;
+      if (t < ntop) { ty = t / tiles_x; tx = t - ty * tiles_x; }
+      else if (t < ntop + ncols_side * nmid) {
+        const int u = t - ntop, r = u / ncols_side, k = u - r * ncols_side;
+        ty = iy0 + r;
+        tx = k < ix0 ? k : ix1 + 1 + (k - ix0);
+      } else {
+        const int u = t - ntop - ncols_side * nmid;
+        ty = iy1 + 1 + u / tiles_x;
+        tx = u % tiles_x;
+      }
+      return false;
+    }
     ty = t / tiles_x;
     tx = (t - ty * tiles_x + 7 * ty) % tiles_x;
     return tx >= 1 && ty >= 1 && tx * TW + TW + HALO <= w && ty * TH + TH + HALO <= h;
@@ -664,12 +722,36 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   const int64_t nring = (int64_t)rband * w + (int64_t)(h > 14 ? h - 14 : 0) * cband;
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
+    // Frames that hold a strip (and whose samples load as pairs) go to rcd_stream, ring included.
+    bool stream = wide_ok && w >= rs::TWS + 2 * rs::HALO && h >= 64;
+#ifdef TDK_EXPERIMENTS
+    if (const char* e = getenv("TDK_RCD_STREAM")) stream = stream && atoi(e) != 0;
+#endif
+    if (stream) {
+      const int nstrips = tdk_div_up(w, rs::TWS);
+      // segments: as many workgroups as the chip holds at once (3 per CU), but no segment shorter than 64 rows (20 rows of
+      // warm-up / drain per segment)
+      int nsegs = (3 * tdk_device_cus()) / nstrips;
+      if (nsegs < 1) nsegs = 1;
+      if (nsegs > h / 64) nsegs = h / 64;
+      int seg_rows = (tdk_div_up(h, nsegs) + 1) & ~1;  // even: segment origins keep the CFA phase
+      if (seg_rows > h) seg_rows = h & ~1;
+      nsegs = tdk_div_up(h, seg_rows);
+      const int nwg = nstrips * nsegs;
+      const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), (int)rs::LDS_BYTES, "tdk_rcd(hipFuncSetAttribute)");
+      if (rc != TDK_OK) return rc;
+      const int nbx = tdk_div_up(w, RING_LEN), nby = tdk_div_up(h - 14, RING_LEN);
+      TDK_LAUNCH("tdk_rcd(border)", (rcd_ring<TI, T>), dim3((unsigned)(2 * nbx + 2 * nby)), dim3(RING_NT), 0, s, in, out, w, h, pattern, nbx, nby);
+      TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), rs::LDS_BYTES, s, in, out, w, h, pattern, nstrips, seg_rows);
+      return TDK_OK;
+    }
+    const int ntiles_launch = tiles_x * tiles_y;
     int grid = tdk_device_cus();  // one resident workgroup per CU
 #ifdef TDK_EXPERIMENTS
-    if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + tiles_x * tiles_y;  // 0 = one item per workgroup
+    if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + ntiles_launch;  // 0 = one item per workgroup
 #endif
-    if (grid > nborder + tiles_x * tiles_y) grid = nborder + tiles_x * tiles_y;
-    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y);
+    if (grid > nborder + ntiles_launch) grid = nborder + ntiles_launch;
+    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y, 0);
   } else {
     TDK_LAUNCH("tdk_rcd(border)", (rcd_border<TI, T>), dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
   }

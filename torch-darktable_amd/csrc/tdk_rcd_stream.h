@@ -1,0 +1,451 @@
+// tdk_rcd_stream.h -- RCD for the part of the image that keeps clear of every border rule: column strips walked downwards.
+// Included by rcd.hip inside its anonymous namespace (shares div_pos / div_signed, Range, CFA_MIN / CFA_MAX).
+//
+// Same nine steps and the same expressions as rcd_phases (reference csrc/debayer/rcd.cu:63-282); what changes is the order in
+// which sites are visited.  rcd_phases owns a 64 x 64 tile per 1024-thread workgroup: the 10-px dependency halo makes it compute
+// 84 x 84 sites per plane (1.72 x the output), its five planes fill the LDS of a CU, and between its seven barriers the 16 waves
+// of the one resident workgroup first all wait for LDS and then all compute.  Here a 512-thread workgroup owns a strip of
+// 108 output columns (128 computed: halo only left and right, 1.19 x) and walks DOWN the image 8 rows per step.  Each of the
+// nine steps runs `lag` rows behind the newest CFA row -- as far as its vertical taps reach:
+//     load 0 | 2.1 lpf 1 | 1.1 v/h_diff 3 | 4.1 p/q_diff 3 | 1.2 VH_dir 4 | 4.2 PQ_dir 4 | 3.1 green 5 | 5.1 colour 7 | 5.2 + output 10
+// so a plane only has to hold the rows its readers still need (`live`) plus the 8 new ones: 47 KB for all ten planes, three
+// workgroups per CU, whose barriers and LDS / VALU phases interleave.  Planes are linear, not rings: after a step every plane
+// slides up by 8 rows (its live rows are copied, 6 % extra LDS traffic), which keeps every tap address of every step a
+// compile-time offset from two per-thread base registers -- a ring would need an address computation per tap row.
+// Thread mapping: wave = row of the step's 8-row block, lane = column PAIR (2 l, 2 l + 1).  Full-density planes are stored
+// de-interleaved by column parity (row = 64 even columns, then 64 odd ones), half-density ones (values at R/B sites, or at odd
+// columns) compacted, so that every access is unit-stride over the lanes: no bank conflicts at wave-uniform rows.  A lane
+// handles both columns of its pair in the full-density steps and the one R/B (or green) site of the pair otherwise.
+// A strip is cut into vertical segments (one workgroup each, 10 + 10 rows of warm-up / drain overlap) so that the launch
+// fills the chip.  The strips cover the whole frame: sites outside a step's border range hold 0 (Cols / Rows below), the
+// [0, 7) ring is border_pixel's (a share per workgroup).  rcd_phases (rcd_interior) keeps the frames the strips do not fit.
+#pragma once
+
+namespace rs {
+
+constexpr int RB = 8, NT = 512, TWS = 108, HALO = 10;
+
+// planes: base (floats), live rows (rows older than the step's 8 new ones that a reader still needs), writer's lag
+constexpr int PAD = 8;
+constexpr int CFA_L = 13, VD_L = 2, HD_L = 1, VH_L = 7, LPF_L = 6, GRN_L = 6, P_L = 2, Q_L = 2, PQ_L = 4, COL_L = 6;
+constexpr int CFA_W = 0, VD_W = 3, HD_W = 3, VH_W = 4, LPF_W = 1, GRN_W = 5, P_W = 3, Q_W = 3, PQ_W = 4, COL_W = 7;
+constexpr int CFA_B = PAD;
+constexpr int VD_B = CFA_B + (CFA_L + RB) * 128;
+constexpr int HD_B = VD_B + (VD_L + RB) * 128;
+constexpr int VH_B = HD_B + (HD_L + RB) * 128;
+constexpr int LPF_B = VH_B + (VH_L + RB) * 128;
+constexpr int GRN_B = LPF_B + (LPF_L + RB) * 64;
+constexpr int P_B = GRN_B + (GRN_L + RB) * 64;
+constexpr int Q_B = P_B + (P_L + RB) * 64;
+constexpr int PQ_B = Q_B + (Q_L + RB) * 64;
+constexpr int COL_B = PQ_B + (PQ_L + RB) * 64;
+constexpr int LDS_FLOATS = COL_B + (COL_L + RB) * 64 + PAD;
+constexpr int VERDICT_WORDS = 4 * 8;  // [step & 3][wave]
+constexpr size_t LDS_BYTES = (size_t)(LDS_FLOATS + VERDICT_WORDS) * sizeof(float);
+static_assert(3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+
+// lags of the steps (rows behind the newest CFA row)
+constexpr int LAG_21 = 1, LAG_11 = 3, LAG_41 = 3, LAG_12 = 4, LAG_42 = 4, LAG_31 = 5, LAG_51 = 7, LAG_52 = 10;
+
+constexpr int fdiv2(int v) { return v >= 0 ? v / 2 : -((1 - v) / 2); }  // floor(v / 2)
+
+// Offset (floats, relative to the lane bases below) of a tap.  `lag` = lag of the READING step; a writer passes its own lag.
+//  full-density plane: tap (dr, dc) seen from a site in a column of parity p
+template <int BASE, int LIVE, int LAGW> constexpr int f128(int lag, int dr, int p, int dc) {
+  return BASE + (LIVE + LAGW - lag + dr) * 128 + ((p + dc) & 1) * 64 + fdiv2(p + dc);
+}
+//  compacted plane: row dr, entry `shift` away from the lane's own entry
+template <int BASE, int LIVE, int LAGW> constexpr int h64(int lag, int dr, int shift) { return BASE + (LIVE + LAGW - lag + dr) * 64 + shift; }
+
+// The slide: float4 slots of all live rows, in plane order; slot k of a plane moves 8 rows up.
+struct SlidePlane { int base, rowlen, live; };
+constexpr SlidePlane SLIDE[10] = {{CFA_B, 128, CFA_L}, {VD_B, 128, VD_L}, {HD_B, 128, HD_L}, {VH_B, 128, VH_L}, {LPF_B, 64, LPF_L},
+                                  {GRN_B, 64, GRN_L},  {P_B, 64, P_L},    {Q_B, 64, Q_L},    {PQ_B, 64, PQ_L},  {COL_B, 64, COL_L}};
+constexpr int slide_slots() {
+  int n = 0;
+  for (int p = 0; p < 10; p++) n += SLIDE[p].live * SLIDE[p].rowlen / 4;
+  return n;
+}
+constexpr int SLIDE_SLOTS = slide_slots();  // 1152
+static_assert(SLIDE_SLOTS <= 3 * NT, "three slots per thread");
+
+// destination offset (floats) of slide slot k and the distance to its source; dst < 0: no slot
+__device__ __forceinline__ void slide_slot(int k, int& dst, int& dist) {
+  dst = -1; dist = 0;
+  int start = 0;
+#pragma unroll
+  for (int p = 0; p < 10; p++) {
+    const int n = SLIDE[p].live * SLIDE[p].rowlen / 4;
+    if (k >= start && k < start + n) { dst = SLIDE[p].base + (k - start) * 4; dist = RB * SLIDE[p].rowlen; }
+    start += n;
+  }
+}
+
+// Border rules (the `row/col >= k && <= size - k` ranges of rcd.cu's kernels): a site outside a step's range holds 0, as in the
+// reference's zero-initialised planes.  Column tests per lane and column parity, computed once per thread (the compiler keeps
+// them as lane masks in SGPRs); row tests are wave-uniform and made per step.
+struct Cols {
+  bool c3[2];   // [3, w - 4]   steps 1.1, 4.1
+  bool c2a[2];  // [2, w - 3]   steps 1.2, 4.2
+  bool c2b[2];  // [2, w - 2]   step 2.1
+  bool c4a[2];  // [4, w - 5]   step 3.1
+  bool c4b[2];  // [4, w - 4]   step 5.1
+  bool img;     // the pair lies inside the frame
+  bool o7[2];   // [7, w - 7) and one of the strip's own columns: the pixel is stored
+};
+struct Rows {  // of the current block, for this wave
+  bool r21, r11, r12, r31, r51, rimg41, rout;
+};
+
+// One step of one wave.  PE = column parity of the R/B sites in this wave's rows of the EVEN-lag steps (odd-lag steps see the
+// other parity: consecutive rows alternate).  b128 / b64: LDS + w * 128 + l / LDS + w * 64 + l.
+template <bool FAST, int PE, typename TI>
+__device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv, const TI* __restrict__ in,
+                                                 int gx_odd, int gy41, int w, int h) {
+  // ---- step 2.1 (lag 1): lpf at the R/B site of the pair
+  {
+    constexpr int L = LAG_21, p = PE ^ (L & 1);
+    auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
+    const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
+    b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = (rv.r21 && cv.c2b[p]) ? v : 0.0f;
+  }
+  // ---- step 1.1 (lag 3): v_diff / h_diff at both columns
+  {
+    constexpr int L = LAG_11;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
+      const float vd = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
+      const float hd = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
+      const bool ok = rv.r11 && cv.c3[p];
+      b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = ok ? vd : 0.0f;
+      b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = ok ? hd : 0.0f;
+    }
+  }
+  // ---- step 4.1 (lag 3): p/q_diff at the odd column
+  {
+    constexpr int L = LAG_41;
+    auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, 1, dc)]; };
+    const float pd = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
+    const float qd = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
+    float pv = pd, qv = qd;
+    // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
+    // rcd.hip); outside the frame: 0
+    const bool inside = rv.rimg41 && cv.img, ranged = rv.r11 && cv.c3[1];
+    if (__builtin_amdgcn_ballot_w64(inside && !ranged) != 0) {
+      if (inside && !ranged) { pv = stale_diff(in, gy41, gx_odd, w, h, true); qv = stale_diff(in, gy41, gx_odd, w, h, false); }
+    }
+    b64[h64<P_B, P_L, P_W>(L, 0, 0)] = inside ? pv : 0.0f;
+    b64[h64<Q_B, Q_L, Q_W>(L, 0, 0)] = inside ? qv : 0.0f;
+  }
+}
+
+template <bool FAST, int PE>
+__device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv) {
+  // ---- step 1.2 (lag 4): VH_dir at both columns
+  {
+    constexpr int L = LAG_12;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      auto vd = [&](int dr) { return b128[f128<VD_B, VD_L, VD_W>(L, dr, p, 0)]; };
+      auto hd = [&](int dc) { return b128[f128<HD_B, HD_L, HD_W>(L, 0, p, dc)]; };
+      const float eps = 1e-10f;
+      const float V_Stat = fmaxf(eps, vd(-1) + vd(0) + vd(1));
+      const float H_Stat = fmaxf(eps, hd(-1) + hd(0) + hd(1));
+      b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = (rv.r12 && cv.c2a[p]) ? div_pos<FAST>(V_Stat, V_Stat + H_Stat) : 0.0f;
+    }
+  }
+  // ---- step 4.2 (lag 4): PQ_dir at the R/B site (column 2 l + p).  p/q slot of odd column 2 j + 1 = entry j; the slots of
+  // (col - 1) | 1 on the neighbour rows: j = l - 1 + p (rcd.cu:166-182)
+  {
+    constexpr int L = LAG_42, p = PE ^ (L & 1), jm = p - 1;
+    auto P = [&](int dr, int sh) { return b64[h64<P_B, P_L, P_W>(L, dr, sh)]; };
+    auto Q = [&](int dr, int sh) { return b64[h64<Q_B, Q_L, Q_W>(L, dr, sh)]; };
+    const float eps = 1e-10f;
+    const float P_Stat = fmaxf(eps, P(-1, jm) + P(0, 0) + P(1, jm + 1));
+    const float Q_Stat = fmaxf(eps, Q(-1, jm + 1) + Q(0, 0) + Q(1, jm));
+    // plain division: a stale slot (see step 4.1) can hold values of samples no range check has seen
+    b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = (rv.r12 && cv.c2a[p]) ? P_Stat / (P_Stat + Q_Stat) : 0.0f;
+  }
+}
+
+// ---- step 3.1 (lag 5): green at the R/B site
+template <bool FAST, int PE>
+__device__ __forceinline__ void step_3_1(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv) {
+  constexpr int L = LAG_31, p = PE ^ (L & 1);
+  auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
+  auto vh = [&](int dr, int dc) { return b128[f128<VH_B, VH_L, VH_W>(L, dr, p, dc)]; };
+  auto lp = [&](int dr, int sh) { return b64[h64<LPF_B, LPF_L, LPF_W>(L, dr, sh)]; };
+  const float eps = 1e-5f;
+  const float VH_c = vh(0, 0);
+  const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
+  const float VH_Disc = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+  const float cfai = a(0, 0);
+  const float N_Grad = eps + fabsf(a(-1, 0) - a(1, 0)) + fabsf(cfai - a(-2, 0)) + fabsf(a(-1, 0) - a(-3, 0)) + fabsf(a(-2, 0) - a(-4, 0));
+  const float S_Grad = eps + fabsf(a(1, 0) - a(-1, 0)) + fabsf(cfai - a(2, 0)) + fabsf(a(1, 0) - a(3, 0)) + fabsf(a(2, 0) - a(4, 0));
+  const float W_Grad = eps + fabsf(a(0, -1) - a(0, 1)) + fabsf(cfai - a(0, -2)) + fabsf(a(0, -1) - a(0, -3)) + fabsf(a(0, -2) - a(0, -4));
+  const float E_Grad = eps + fabsf(a(0, 1) - a(0, -1)) + fabsf(cfai - a(0, 2)) + fabsf(a(0, 1) - a(0, 3)) + fabsf(a(0, 2) - a(0, 4));
+  const float lpfi = lp(0, 0);
+  const float N_Est = div_pos<FAST>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
+  const float S_Est = div_pos<FAST>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
+  const float W_Est = div_pos<FAST>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
+  const float E_Est = div_pos<FAST>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
+  const float V_Est = div_pos<FAST>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
+  const float H_Est = div_pos<FAST>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
+  b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = (rv.r31 && cv.c4a[p]) ? mixf(V_Est, H_Est, VH_Disc) : 0.0f;
+}
+
+// ---- step 5.1 (lag 7): the opposite colour at the R/B site.  `lanes_ok`: lanes whose numerators count in the wave's
+// fast-division test (the outermost columns compute on garbage).
+template <bool FAST, int PE>
+__device__ __forceinline__ void step_5_1(float* __restrict__ b128, float* __restrict__ b64, bool lanes_ok, const Cols& cv, const Rows& rv) {
+  constexpr int L = LAG_51, p = PE ^ (L & 1);
+  auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
+  auto pq = [&](int dr, int sh) { return b64[h64<PQ_B, PQ_L, PQ_W>(L, dr, sh)]; };
+  // green of R/B site (row + dr, col + dc): rows of the same parity keep the lane's entry shifted by dc / 2, the other rows
+  // hold their R/B sites on the other column parity: entry l + (p + dc - (1 - p)) / 2
+  auto G = [&](int dr, int dc) { return b64[h64<GRN_B, GRN_L, GRN_W>(L, dr, (dr & 1) ? fdiv2(2 * p + dc - 1) : dc / 2)]; };
+  constexpr int s = p - 1;  // entry of slot (col - 1) / 2 on the neighbour rows (rcd.cu:199-207)
+  const float eps = 1e-5f;
+  const float PQ_c = pq(0, 0);
+  const float PQ_n = 0.25f * (pq(-1, s) + pq(-1, s + 1) + pq(1, s) + pq(1, s + 1));
+  const float PQ_Disc = (fabsf(0.5f - PQ_c) < fabsf(0.5f - PQ_n)) ? PQ_n : PQ_c;
+  const float g0 = G(0, 0);
+  const float NW_Grad = eps + fabsf(a(-1, -1) - a(1, 1)) + fabsf(a(-1, -1) - a(-3, -3)) + fabsf(g0 - G(-2, -2));
+  const float NE_Grad = eps + fabsf(a(-1, 1) - a(1, -1)) + fabsf(a(-1, 1) - a(-3, 3)) + fabsf(g0 - G(-2, 2));
+  const float SW_Grad = eps + fabsf(a(-1, 1) - a(1, -1)) + fabsf(a(1, -1) - a(3, -3)) + fabsf(g0 - G(2, -2));
+  const float SE_Grad = eps + fabsf(a(-1, -1) - a(1, 1)) + fabsf(a(1, 1) - a(3, 3)) + fabsf(g0 - G(2, 2));
+  const float NW_Est = a(-1, -1) - G(-1, -1);
+  const float NE_Est = a(-1, 1) - G(-1, 1);
+  const float SW_Est = a(1, -1) - G(1, -1);
+  const float SE_Est = a(1, 1) - G(1, 1);
+  float num[2] = {NW_Grad * SE_Est + SE_Grad * NW_Est, NE_Grad * SW_Est + SW_Grad * NE_Est};
+  float den[2] = {NW_Grad + SE_Grad, NE_Grad + SW_Grad};
+  const bool ok = rv.r51 && cv.c4b[p];
+  if (!(lanes_ok && ok)) { num[0] = num[1] = 1.0f; den[0] = den[1] = 1.0f; }
+  float est[2];  // P_Est, Q_Est
+  div_signed<FAST>(num, den, est);
+  b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = ok ? g0 + mixf(est[0], est[1], PQ_Disc) : 0.0f;
+}
+
+// ---- step 5.2 (lag 10) at the green site of the pair + the two finished pixels of the pair
+template <bool FAST, int PE, typename T>
+__device__ __forceinline__ void step_5_2_out(float* __restrict__ b128, float* __restrict__ b64, bool red_row, T* __restrict__ dst, const Cols& cv, const Rows& rv) {
+  const bool st_e = rv.rout && cv.o7[0], st_o = rv.rout && cv.o7[1];  // column 2 l / 2 l + 1 is stored
+  const bool lanes_ok = st_e || st_o;
+  constexpr int L = LAG_52, p = PE ^ (L & 1), pg = 1 - p;  // R/B sites on parity p, the green site of the pair on pg
+  auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, pg, dc)]; };
+  auto vh = [&](int dr, int dc) { return b128[f128<VH_B, VH_L, VH_W>(L, dr, pg, dc)]; };
+  auto grn = [&](int dr, int sh) { return b64[h64<GRN_B, GRN_L, GRN_W>(L, dr, sh)]; };
+  auto col = [&](int dr, int sh) { return b64[h64<COL_B, COL_L, COL_W>(L, dr, sh)]; };
+  const float eps = 1e-5f;
+  const float VH_c = vh(0, 0);
+  const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
+  const float VH_Disc = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+  const float g = a(0, 0);
+  const float N1 = eps + fabsf(g - a(-2, 0));
+  const float S1 = eps + fabsf(g - a(2, 0));
+  const float W1 = eps + fabsf(g - a(0, -2));
+  const float E1 = eps + fabsf(g - a(0, 2));
+  // green at the four R/B neighbours: above / below the lane's own entry (those rows hold their R/B sites on this column's
+  // parity), left / right the entries of columns col -+ 1 of this row
+  const float gN = grn(-1, 0), gS = grn(1, 0), gW = grn(0, -p), gE = grn(0, 1 - p);
+  // colour of this row's R/B sites (`own`): native left / right, from step 5.1 above / below; the other colour the other way round
+  float num[4], den[4], est[4];  // V_Est, H_Est of `own`, then of the other colour
+#pragma unroll
+  for (int ci = 0; ci < 2; ci++) {
+    float cN, cS, cW, cE, cN3, cS3, cW3, cE3;
+    if (ci == 0) {
+      cW = a(0, -1); cE = a(0, 1); cW3 = a(0, -3); cE3 = a(0, 3);
+      cN = col(-1, 0); cS = col(1, 0); cN3 = col(-3, 0); cS3 = col(3, 0);
+    } else {
+      cW = col(0, -p); cE = col(0, 1 - p); cW3 = col(0, -p - 1); cE3 = col(0, 2 - p);
+      cN = a(-1, 0); cS = a(1, 0); cN3 = a(-3, 0); cS3 = a(3, 0);
+    }
+    const float SNabs = fabsf(cN - cS);
+    const float EWabs = fabsf(cW - cE);
+    const float N_Grad = N1 + SNabs + fabsf(cN - cN3);
+    const float S_Grad = S1 + SNabs + fabsf(cS - cS3);
+    const float W_Grad = W1 + EWabs + fabsf(cW - cW3);
+    const float E_Grad = E1 + EWabs + fabsf(cE - cE3);
+    const float N_Est = cN - gN;
+    const float S_Est = cS - gS;
+    const float W_Est = cW - gW;
+    const float E_Est = cE - gE;
+    num[2 * ci] = N_Grad * S_Est + S_Grad * N_Est;
+    den[2 * ci] = N_Grad + S_Grad;
+    num[2 * ci + 1] = E_Grad * W_Est + W_Grad * E_Est;
+    den[2 * ci + 1] = E_Grad + W_Grad;
+  }
+  if (!lanes_ok) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { num[i] = 1.0f; den[i] = 1.0f; }
+  }
+  div_signed<FAST>(num, den, est);
+  const float own = fmaxf(g + mixf(est[0], est[1], VH_Disc), 0.0f), oth = fmaxf(g + mixf(est[2], est[3], VH_Disc), 0.0f);
+  float gpx[3] = {red_row ? own : oth, fmaxf(g, 0.0f), red_row ? oth : own};
+  // the R/B pixel of the pair: native, green from step 3.1, other colour from step 5.1
+  const float native = fmaxf(b128[f128<CFA_B, CFA_L, CFA_W>(L, 0, p, 0)], 0.0f), green = fmaxf(grn(0, 0), 0.0f), other = fmaxf(col(0, 0), 0.0f);
+  float rbpx[3] = {red_row ? native : other, green, red_row ? other : native};
+  // column 2 l first: the R/B pixel when the R/B sites of this row sit on even columns
+  const float f0 = p == 0 ? rbpx[0] : gpx[0], f1 = p == 0 ? rbpx[1] : gpx[1], f2 = p == 0 ? rbpx[2] : gpx[2];
+  const float s0 = p == 0 ? gpx[0] : rbpx[0], s1 = p == 0 ? gpx[1] : rbpx[1], s2 = p == 0 ? gpx[2] : rbpx[2];
+  if (st_e && st_o) {
+    if constexpr (sizeof(T) == 4) {
+      struct alignas(8) px6 { float a, b, c, d, e, f; };
+      *reinterpret_cast<px6*>(dst) = px6{f0, f1, f2, s0, s1, s2};
+    } else {
+      struct alignas(4) pair6 { __half2 a, b, c; };
+      *reinterpret_cast<pair6*>(dst) = pair6{__floats2half2_rn(f0, f1), __floats2half2_rn(f2, s0), __floats2half2_rn(s1, s2)};
+    }
+  } else if (st_e) {  // the frame's last stored column is even (w - 8) ...
+    st(dst, 0, f0); st(dst, 1, f1); st(dst, 2, f2);
+  } else if (st_o) {  // ... its first one odd (7)
+    st(dst, 3, s0); st(dst, 4, s1); st(dst, 5, s2);
+  }
+}
+
+template <typename TI> struct Pair;
+template <> struct Pair<float> {
+  float2 v;
+  __device__ __forceinline__ void fetch(const float* p) { v = *reinterpret_cast<const float2*>(p); }
+  __device__ __forceinline__ float2 get() const { return v; }
+};
+template <> struct Pair<__half> {
+  uint32_t v;
+  __device__ __forceinline__ void fetch(const __half* p) { v = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ float2 get() const { return __half22float2(__builtin_bit_cast(__half2, v)); }
+};
+
+__device__ __forceinline__ void wg_barrier() {  // orders LDS traffic only: the prefetched samples stay in flight across it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Workgroup = one segment of one strip (grid: nstrips * nsegs), covering the whole frame but the [0, 7) border ring (rcd_border's:
+// its nine-neighbour arithmetic inside this kernel would cost it two waves per SIMD in registers).
+// Requires: w even and >= TWS + 2 HALO, base pointer aligned for pair loads (host-checked).
+template <typename TI, typename T>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void rcd_stream(const TI* __restrict__ in, T* __restrict__ out, int w, int h,
+                                                                                              uint32_t pattern, int nstrips, int seg_rows) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+
+  const int strip = (int)blockIdx.x % nstrips, seg = (int)blockIdx.x / nstrips;
+  // the last strip / segment is moved back so that it ends at the frame's edge (it recomputes what its neighbour also writes)
+  const int xs = min(strip * TWS, w - TWS), ys = min(seg * seg_rows, h - seg_rows);
+  const int gx0 = xs - HALO, gy0 = ys - HALO;  // frame position of window column 0 / row 0; both even
+  const int nsteps = (seg_rows + 2 * HALO + RB - 1) / RB;
+  float* b128 = lds + wv * 128 + l;
+  float* b64 = lds + wv * 64 + l;
+  uint32_t* verdict = reinterpret_cast<uint32_t*>(lds + LDS_FLOATS);
+
+  // row parity: R/B column parity of window row (wv - lag) for even lag
+  const int rowpar0 = cfa_color(0, 0, pattern) & 1, rowpar1 = cfa_color(1, 0, pattern) & 1;
+  const int pe = ((gy0 + wv) & 1) ? rowpar1 : rowpar0;
+  // colour of the R/B sites in this wave's output rows (lag 10: even)
+  const bool red_row = cfa_color(gy0 + wv, pe, pattern) == 0;
+  const bool lanes_51 = l >= 3 && l < 61;  // the pairs whose step-5.1 colour a stored pixel can read (3 columns away)
+  const bool own = l >= HALO / 2 && l < (HALO + TWS) / 2;  // the strip's own pairs
+
+  Cols cv;
+  const int gxe = gx0 + 2 * l;
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int gx = gxe + p;
+    cv.c3[p] = gx >= 3 && gx <= w - 4;
+    cv.c2a[p] = gx >= 2 && gx <= w - 3;
+    cv.c2b[p] = gx >= 2 && gx <= w - 2;
+    cv.c4a[p] = gx >= 4 && gx <= w - 5;
+    cv.c4b[p] = gx >= 4 && gx <= w - 4;
+    cv.o7[p] = own && gx >= 7 && gx < w - 7;
+  }
+  cv.img = gxe >= 0 && gxe < w;  // w even: a pair is inside or outside as a whole
+
+  // slide slots of this thread
+  int sd[3], sdist[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) slide_slot(tid + k * NT, sd[k], sdist[k]);
+  static_assert(SLIDE_SLOTS >= 2 * NT && (SLIDE_SLOTS - 2 * NT) % 64 == 0, "slots 0 and 1 exist for every thread, slot 2 for whole waves");
+  const bool third = wv < (SLIDE_SLOTS - 2 * NT) / 64;  // wave-uniform
+
+  // samples of window row 8 b + wv, columns 2 l, 2 l + 1; outside the frame: 0
+  Pair<TI> st;
+  bool st_in = false;
+  auto prefetch = [&](int b) {
+    const int gy = gy0 + RB * b + wv;
+    st_in = cv.img && gy >= 0 && gy < h;
+    if (st_in) st.fetch(in + (size_t)gy * w + gxe);
+  };
+  prefetch(0);
+  bool ok1 = false, ok2 = false;  // range verdicts of the two previous blocks
+
+  for (int b = 0; b < nsteps; b++) {
+    // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
+    if (b > 0) {
+      const float4 s0 = *reinterpret_cast<const float4*>(lds + sd[0] + sdist[0]);
+      const float4 s1 = *reinterpret_cast<const float4*>(lds + sd[1] + sdist[1]);
+      float4 s2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (third) s2 = *reinterpret_cast<const float4*>(lds + sd[2] + sdist[2]);
+      wg_barrier();
+      *reinterpret_cast<float4*>(lds + sd[0]) = s0;
+      *reinterpret_cast<float4*>(lds + sd[1]) = s1;
+      if (third) *reinterpret_cast<float4*>(lds + sd[2]) = s2;
+    }
+    // ---- the new CFA rows (max(0, in)), their range verdict, and the next block's samples on their way
+    {
+      float a0 = 0.0f, a1 = 0.0f;
+      if (st_in) {
+        const float2 s2 = st.get();
+        a0 = fmaxf(0.0f, s2.x);
+        a1 = fmaxf(0.0f, s2.y);
+      }
+      b128[f128<CFA_B, CFA_L, CFA_W>(0, 0, 0, 0)] = a0;
+      b128[f128<CFA_B, CFA_L, CFA_W>(0, 0, 1, 0)] = a1;
+      Range rg;
+      rg.add(a0);
+      rg.add(a1);
+      const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
+      if (l == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      if (b + 1 < nsteps) prefetch(b + 1);
+    }
+    wg_barrier();
+    uint32_t all = 1u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) all &= verdict[(b & 3) * 8 + k];
+    const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
+    const bool fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
+    ok2 = ok1; ok1 = ok0;
+
+    // frame rows of this wave's sites in the steps of this block, and their border rules
+    const int gyb = gy0 + RB * b + wv;  // row of lag 0
+    Rows rv;
+    { const int gy = gyb - LAG_21; rv.r21 = gy >= 2 && gy <= h - 2; }
+    { const int gy = gyb - LAG_11; rv.r11 = gy >= 3 && gy <= h - 4; rv.rimg41 = gy >= 0 && gy < h; }
+    { const int gy = gyb - LAG_12; rv.r12 = gy >= 2 && gy <= h - 3; }
+    { const int gy = gyb - LAG_31; rv.r31 = gy >= 4 && gy <= h - 5; }
+    { const int gy = gyb - LAG_51; rv.r51 = gy >= 4 && gy <= h - 4; }
+    const int orow = RB * b - LAG_52 + wv, gyo = gy0 + orow;
+    rv.rout = orow >= HALO && orow < HALO + seg_rows && gyo >= 7 && gyo < h - 7;
+    T* dst = out + ((size_t)gyo * w + gxe) * 3;
+
+#define RS_STEP(FASTV, PEV)                                                                                \
+  do {                                                                                                     \
+    step_2_1_1_1_4_1<FASTV, PEV, TI>(b128, b64, cv, rv, in, gxe + 1, gyb - LAG_41, w, h);                  \
+    wg_barrier();                                                                                          \
+    step_1_2_4_2<FASTV, PEV>(b128, b64, cv, rv);                                                           \
+    wg_barrier();                                                                                          \
+    step_3_1<FASTV, PEV>(b128, b64, cv, rv);                                                               \
+    wg_barrier();                                                                                          \
+    step_5_1<FASTV, PEV>(b128, b64, lanes_51, cv, rv);                                                     \
+    wg_barrier();                                                                                          \
+    step_5_2_out<FASTV, PEV, T>(b128, b64, red_row, dst, cv, rv);                                          \
+  } while (0)
+    if (fast) { if (pe) RS_STEP(true, 1); else RS_STEP(true, 0); }
+    else { if (pe) RS_STEP(false, 1); else RS_STEP(false, 0); }
+#undef RS_STEP
+  }
+}
+
+}  // namespace rs
