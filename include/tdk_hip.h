@@ -78,6 +78,10 @@ int tdk_ppg(const void* bayer, void* rgb, void* workspace, int width, int height
  * with the reference's first-call (zero-initialised scratch) semantics.  width must be even. */
 size_t tdk_rcd_workspace_bytes(int width, int height);
 int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream);
+/* Test hook, process-wide: 0 = automatic (frames at least 128 x 64 whose rows load as sample pairs: column strips walked
+ * down the frame, csrc/tdk_rcd_stream.h; otherwise 64 x 64 LDS tiles), 1 = always the tile kernel.  Both give the same
+ * bits; tests compare them. */
+int tdk_rcd_select_path(int path);
 
 /* decode12_float -> apply_white_balance -> RCD.process as ONE call -- the head of the reference pipeline
  * (torch_darktable/pipeline/image_processor.py:190-255: load_bytes, debayer) -- bit for bit the result of the three

@@ -116,6 +116,31 @@ def test_rcd_bit_exact(td, oracle, dev, scene, pattern, size):
     assert bad.size == 0, f'{len(bad)} mismatches, first at {bad[:5].tolist()}, max |d| {np.abs(got - ref).max()}'
 
 
+@pytest.mark.parametrize('pattern', PATTERNS)
+@pytest.mark.parametrize('size', [(64, 128), (203, 300), (130, 258), (321, 128)])
+def test_rcd_strips_equal_tiles(td, oracle, dev, scene, pattern, size):
+    """Frames of at least 128 x 64 run as column strips walked down the frame (csrc/tdk_rcd_stream.h), smaller ones as
+    64 x 64 LDS tiles; both must give the oracle's bits -- here on the same input, fp32 and fp16 storage, with frames that
+    hold one strip exactly, several strips and segments, an odd height, and a last strip / segment moved back onto its
+    neighbour."""
+    h, w = size
+    bayer = oracle.mosaic(scene(h, w, 17), oracle.PATTERNS[pattern])
+    ref = oracle.rcd(bayer, oracle.PATTERNS[pattern])
+    b16 = bayer.astype(np.float16)
+    ref16 = oracle.rcd(b16.astype(np.float32), oracle.PATTERNS[pattern]).astype(np.float16)
+    ws = td.RCD(dev, (w, h), td.BayerPattern[pattern])
+    strips, strips16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
+    from torch_darktable._native import lib
+    assert lib.tdk_rcd_select_path(1) == 0
+    try:
+        tiles, tiles16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
+    finally:
+        assert lib.tdk_rcd_select_path(0) == 0
+    for name, got, want in (('strips', strips, ref), ('tiles', tiles, ref), ('strips f16', strips16, ref16), ('tiles f16', tiles16, ref16)):
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, f'{name}: {len(bad)} mismatches, first at {bad[:5].tolist()}'
+
+
 @pytest.mark.parametrize('size', [(2, 2), (2, 4), (4, 4), (4, 6), (6, 8), (10, 14), (14, 16), (16, 16), (7, 5), (3, 64), (64, 2)])
 def test_tiny_images_every_stencil_op(td, oracle, dev, size):
     """Images smaller than every halo / tile / ring: all pixels are border cases (the oracle was run

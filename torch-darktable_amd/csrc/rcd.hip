@@ -26,6 +26,8 @@
 // border ring (3x3 average + PPG-style green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is
 // computed by the first ~100 workgroups of the same launch.  Arithmetic: same operation order as
 // the oracle, no FMA contraction, IEEE divides -> bit-exact.
+#include <atomic>
+
 #include "tdk_fastdiv.h"
 #include "tdk_stencils.h"
 
@@ -708,6 +710,9 @@ __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T*
   }
 }
 
+// test hook (tdk_rcd_select_path): take the tile kernel even where the strips apply
+static std::atomic<int> g_force_tile_path{0};
+
 template <typename TI, typename T>
 int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
   const TI* in = reinterpret_cast<const TI*>(bayer);
@@ -723,7 +728,7 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
     // Frames that hold a strip (and whose samples load as pairs) go to rcd_stream, ring included.
-    bool stream = wide_ok && w >= rs::TWS + 2 * rs::HALO && h >= 64;
+    bool stream = wide_ok && w >= rs::TWS + 2 * rs::HALO && h >= 64 && !g_force_tile_path.load(std::memory_order_relaxed);
 #ifdef TDK_EXPERIMENTS
     if (const char* e = getenv("TDK_RCD_STREAM")) stream = stream && atoi(e) != 0;
 #endif
@@ -763,6 +768,12 @@ template <typename T> int launch(const void* bayer, void* rgb, int w, int h, uin
 }  // namespace
 
 TDK_EXPORT size_t tdk_rcd_workspace_bytes(int, int) { return 0; }
+
+TDK_EXPORT int tdk_rcd_select_path(int path) {
+  TDK_REQUIRE(path == 0 || path == 1, "tdk_rcd_select_path: path must be 0 (automatic) or 1 (tile kernel)");
+  g_force_tile_path.store(path, std::memory_order_relaxed);
+  return TDK_OK;
+}
 
 TDK_EXPORT int tdk_rcd(const void* bayer, void* rgb, void* /*workspace*/, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream) {
   TDK_REQUIRE(bayer && rgb, "tdk_rcd: null pointer");

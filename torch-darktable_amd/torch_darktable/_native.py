@@ -31,6 +31,7 @@ SIGNATURES = {
   'tdk_ppg': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_float, c_int, c_void_p]),
   'tdk_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_void_p]),
+  'tdk_rcd_select_path': (c_int, [c_int]),
   'tdk_decode12_wb_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_decode12_wb_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p]),
   'tdk_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
