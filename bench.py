@@ -212,6 +212,8 @@ def launch_bytes_per_px(kernel: str, s: int) -> float | None:
         'tdk_tonemap': 3 * s + 3,
         'tdk_image_metrics_accumulate': 3 * s / 64.0,          # stride-8 sample grid
         'tdk_image_metrics_finish': 0.0,
+        'tdk_rcd(border)': 0.0,                                # the 7-px ring: its bytes are in tdk_rcd's boundary count
+        'tdk_bilateral(tables)': 0.0,                          # per-launch axis tables, a few hundred KB
     }
     return table.get(kernel)
 
