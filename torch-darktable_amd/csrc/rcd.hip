@@ -743,11 +743,15 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
       if (seg_rows > h) seg_rows = h & ~1;
       nsegs = tdk_div_up(h, seg_rows);
       const int nwg = nstrips * nsegs;
-      const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), (int)rs::LDS_BYTES, "tdk_rcd(hipFuncSetAttribute)");
+      const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
       if (rc != TDK_OK) return rc;
       const int nbx = tdk_div_up(w, RING_LEN), nby = tdk_div_up(h - 14, RING_LEN);
       TDK_LAUNCH("tdk_rcd(border)", (rcd_ring<TI, T>), dim3((unsigned)(2 * nbx + 2 * nby)), dim3(RING_NT), 0, s, in, out, w, h, pattern, nbx, nby);
-      TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), rs::LDS_BYTES, s, in, out, w, h, pattern, nstrips, seg_rows);
+      size_t strip_lds = rs::LDS_BYTES;
+#ifdef TDK_EXPERIMENTS
+      if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
+#endif
+      TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows);
       return TDK_OK;
     }
     const int ntiles_launch = tiles_x * tiles_y;
