@@ -185,10 +185,13 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
 // piece and its 1-px surround (border_pixel evaluates it nine times per pixel: 25 us of dependent loads at 12 MP), then the
 // red/blue fill from the staged values.  Same expressions as border_pixel.  Needs w > 14 and h > 14.
 constexpr int RING_LEN = 32, RING_NT = 320;  // (32 + 2) x 9 = 306 staged positions: one per thread
+constexpr int RING_TMP = (RING_LEN + 2) * 9;
+
+// piece number b of the ring on `nthreads` threads (all of them must call: barriers inside); tmp: 3 * RING_TMP floats of LDS
 template <typename TI, typename T>
-__global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nbx, int nby) {
-  __shared__ float tmp[3][(RING_LEN + 2) * 9];
-  int b = blockIdx.x, x0, y0, bw, bh;
+__device__ __forceinline__ void ring_piece(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nbx, int nby, int b,
+                                           float* __restrict__ tmp, int nthreads) {
+  int x0, y0, bw, bh;
   if (b < 2 * nbx) {  // top, then bottom band
     x0 = (b % nbx) * RING_LEN; y0 = b < nbx ? 0 : h - 7;
     bw = min(RING_LEN, w - x0); bh = 7;
@@ -198,16 +201,16 @@ __global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T
     bw = 7; bh = min(RING_LEN, h - 7 - y0);
   }
   const int tw = bw + 2, th = bh + 2;
-  for (int i = threadIdx.x; i < tw * th; i += RING_NT) {
+  for (int i = threadIdx.x; i < tw * th; i += nthreads) {
     const int ty = i / tw, tx = i - ty * tw;
     const f3 t = border_temp(in, x0 - 1 + tx, y0 - 1 + ty, w, h, pattern);
-    tmp[0][i] = fmaxf(0.0f, t.x); tmp[1][i] = fmaxf(0.0f, t.y); tmp[2][i] = fmaxf(0.0f, t.z);
+    tmp[i] = fmaxf(0.0f, t.x); tmp[RING_TMP + i] = fmaxf(0.0f, t.y); tmp[2 * RING_TMP + i] = fmaxf(0.0f, t.z);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < bw * bh; i += RING_NT) {
+  for (int i = threadIdx.x; i < bw * bh; i += nthreads) {
     const int py = i / bw, px = i - py * bw, x = x0 + px, y = y0 + py;
     const int c0 = (py + 1) * tw + px + 1;
-    auto nb = [&](int dx, int dy) { const int q = c0 + dy * tw + dx; return mk3(tmp[0][q], tmp[1][q], tmp[2][q]); };
+    auto nb = [&](int dx, int dy) { const int q = c0 + dy * tw + dx; return mk3(tmp[q], tmp[RING_TMP + q], tmp[2 * RING_TMP + q]); };
     f3 col = nb(0, 0);
     if (y > 0 && x > 0 && x < w - 1 && y < h - 1) col = ppg_redblue(nb, col, cfa_color(y, x, pattern), cfa_color(y, x + 1, pattern) == 0);
     const size_t p = (size_t)y * w + x;
@@ -215,6 +218,12 @@ __global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T
     st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
     st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
   }
+}
+
+template <typename TI, typename T>
+__global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nbx, int nby) {
+  __shared__ float tmp[3 * RING_TMP];
+  ring_piece(in, out, w, h, pattern, nbx, nby, (int)blockIdx.x, tmp, RING_NT);
 }
 
 // One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
@@ -745,13 +754,12 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
       const int nwg = nstrips * nsegs;
       const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
       if (rc != TDK_OK) return rc;
-      const int nbx = tdk_div_up(w, RING_LEN), nby = tdk_div_up(h - 14, RING_LEN);
-      TDK_LAUNCH("tdk_rcd(border)", (rcd_ring<TI, T>), dim3((unsigned)(2 * nbx + 2 * nby)), dim3(RING_NT), 0, s, in, out, w, h, pattern, nbx, nby);
+      const int nbx = tdk_div_up(w, RING_LEN), nby = tdk_div_up(h - 14, RING_LEN);  // ring pieces: a share of the strip workgroups takes one each
       size_t strip_lds = rs::LDS_BYTES;
 #ifdef TDK_EXPERIMENTS
       if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
 #endif
-      TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows);
+      TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
       return TDK_OK;
     }
     const int ntiles_launch = tiles_x * tiles_y;

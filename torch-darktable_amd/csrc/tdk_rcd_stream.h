@@ -323,14 +323,20 @@ __device__ __forceinline__ void wg_barrier() {  // orders LDS traffic only: the 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Workgroup = one segment of one strip (grid: nstrips * nsegs), covering the whole frame but the [0, 7) border ring (rcd_border's:
-// its nine-neighbour arithmetic inside this kernel would cost it two waves per SIMD in registers).
+// Workgroup = one segment of one strip (grid: nstrips * nsegs), covering the whole frame; the [0, 7) border ring is staged in
+// pieces (ring_piece in rcd.hip: 30 registers; border_pixel's nine-neighbour form cost this kernel two waves per SIMD).
 // Requires: w even and >= TWS + 2 HALO, base pointer aligned for pair loads (host-checked).
 template <typename TI, typename T>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void rcd_stream(const TI* __restrict__ in, T* __restrict__ out, int w, int h,
-                                                                                              uint32_t pattern, int nstrips, int seg_rows) {
+                                                                                              uint32_t pattern, int nstrips, int seg_rows, int nbx, int nby) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+  // the [0, 7) border ring (independent of the strips: disjoint output pixels, input read-only): one piece per workgroup until
+  // the pieces run out, staged through the plane area
+  for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
+    ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
+    __syncthreads();
+  }
 
   const int strip = (int)blockIdx.x % nstrips, seg = (int)blockIdx.x / nstrips;
   // the last strip / segment is moved back so that it ends at the frame's edge (it recomputes what its neighbour also writes)
