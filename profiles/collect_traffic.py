@@ -40,7 +40,6 @@ KERNELS = {
     # column strips: one 4-B (fp16) / 8-B (fp32) sample pair per lane and step, 12-B / 24-B pixel pairs out
     'rcd_stream': ('tdk_rcd', False),
     'rcd_border': ('tdk_rcd(border)', False),
-    'rcd_ring': ('tdk_rcd(border)', False),
     'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
     'bilateral_axis_tables_kernel': ('tdk_bilateral(tables)', False),
     'metrics_kernel': ('tdk_image_metrics_accumulate', False),

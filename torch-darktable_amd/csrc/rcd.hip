@@ -180,11 +180,11 @@ __global__ __launch_bounds__(256) void rcd_border(const TI* __restrict__ in, T* 
   border_pixel(in, out, w, h, pattern, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
-// The ring in two passes through LDS (used beside rcd_stream): a workgroup owns a 32 x 7 (top / bottom bands) or 7 x 32 (left /
-// right bands, rows [7, h - 7)) piece of the ring, computes the intermediate image of border_temp() ONCE per position of the
-// piece and its 1-px surround (border_pixel evaluates it nine times per pixel: 25 us of dependent loads at 12 MP), then the
-// red/blue fill from the staged values.  Same expressions as border_pixel.  Needs w > 14 and h > 14.
-constexpr int RING_LEN = 32, RING_NT = 320;  // (32 + 2) x 9 = 306 staged positions: one per thread
+// The ring in two passes through LDS (the strips launch, tdk_rcd_stream.h): a piece = 32 x 7 pixels of the top / bottom bands or
+// 7 x 32 of the left / right bands (rows [7, h - 7)); the intermediate image of border_temp() is computed ONCE per position of
+// the piece and its 1-px surround (border_pixel evaluates it nine times per pixel: 25 us of dependent loads at 12 MP as a
+// kernel of its own), then the red/blue fill from the staged values.  Same expressions as border_pixel.  Needs w > 14, h > 14.
+constexpr int RING_LEN = 32;  // (32 + 2) x 9 = 306 staged positions
 constexpr int RING_TMP = (RING_LEN + 2) * 9;
 
 // piece number b of the ring on `nthreads` threads (all of them must call: barriers inside); tmp: 3 * RING_TMP floats of LDS
@@ -218,12 +218,6 @@ __device__ __forceinline__ void ring_piece(const TI* __restrict__ in, T* __restr
     st(out, p * 3 + 1, fmaxf(col.y, 0.0f));
     st(out, p * 3 + 2, fmaxf(col.z, 0.0f));
   }
-}
-
-template <typename TI, typename T>
-__global__ __launch_bounds__(RING_NT) void rcd_ring(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nbx, int nby) {
-  __shared__ float tmp[3 * RING_TMP];
-  ring_piece(in, out, w, h, pattern, nbx, nby, (int)blockIdx.x, tmp, RING_NT);
 }
 
 // One 64 x 64 tile.  INTERIOR = the tile and its 10-px halo keep clear of every image-border rule
@@ -662,31 +656,13 @@ __device__ __forceinline__ bool load_tile(const TI* __restrict__ in, int w, int 
 // tiles spread over the workgroups instead of landing on the same two.
 template <typename TI, typename T>   // TI: storage type of the mosaic, T: of the RGB result
 __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int wide_ok, int nborder,
-                                                    int tiles_x, int tiles_y, int border_only) {
+                                                    int tiles_x, int tiles_y) {
   extern __shared__ float lds[];
   const int G = (int)gridDim.x;
   for (int i = (int)blockIdx.x; i < nborder; i += G) border_pixel(in, out, w, h, pattern, (int64_t)i * NT + threadIdx.x);
 
-  // border_only (the interior goes to rcd_stream): the work list holds only the tiles that touch a border rule -- the first and
-  // last tile rows completely, the first and last column(s) of the rows in between
-  const int ix0 = 1, ix1 = (w - TW - HALO) / TW, iy0 = 1, iy1 = (h - TH - HALO) / TH;  // interior tiles: [ix0, ix1] x [iy0, iy1]
-  const int ncols_side = tiles_x - (ix1 - ix0 + 1), nmid = iy1 - iy0 + 1;              // border tiles per middle row; middle rows
-  const int ntiles = border_only ? tiles_x * (tiles_y - nmid) + ncols_side * nmid : tiles_x * tiles_y;
+  const int ntiles = tiles_x * tiles_y;
   auto locate = [&](int t, int& tx, int& ty) -> bool {  // tile number -> position; true: clear of every image-border rule
-    if (border_only) {
-      const int ntop = tiles_x * iy0;
-      if (t < ntop) { ty = t / tiles_x; tx = t - ty * tiles_x; }
-      else if (t < ntop + ncols_side * nmid) {
-        const int u = t - ntop, r = u / ncols_side, k = u - r * ncols_side;
-        ty = iy0 + r;
-        tx = k < ix0 ? k : ix1 + 1 + (k - ix0);
-      } else {
-        const int u = t - ntop - ncols_side * nmid;
-        ty = iy1 + 1 + u / tiles_x;
-        tx = u % tiles_x;
-      }
-      return false;
-    }
     ty = t / tiles_x;
     tx = (t - ty * tiles_x + 7 * ty) % tiles_x;
     return tx >= 1 && ty >= 1 && tx * TW + TW + HALO <= w && ty * TH + TH + HALO <= h;
@@ -768,7 +744,7 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
     if (const char* e = getenv("TDK_RCD_GRID")) grid = atoi(e) > 0 ? atoi(e) : nborder + ntiles_launch;  // 0 = one item per workgroup
 #endif
     if (grid > nborder + ntiles_launch) grid = nborder + ntiles_launch;
-    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y, 0);
+    TDK_LAUNCH("tdk_rcd", (rcd_interior<TI, T>), dim3((unsigned)grid), dim3(NT), lds_bytes, s, in, out, w, h, pattern, wide_ok, nborder, tiles_x, tiles_y);
   } else {
     TDK_LAUNCH("tdk_rcd(border)", (rcd_border<TI, T>), dim3((unsigned)tdk_div_up64(nring, 256)), dim3(256), 0, s, in, out, w, h, pattern);
   }
