@@ -1,6 +1,6 @@
 """Experiment: clock64() deltas per phase of one workgroup of the bilateral tile kernel, from a library built with
 -DTDK_EXPERIMENTS -DTDK_BIL_TIMING=1 (only bilateral.hip recompiled; the default build compiles no experiment hooks):  python profiles/bilateral_phase_exp.py variants/bil_timing.so
-Phases: 0 setup (tables, sample tile, zero grid), 1 splat, 2 blur x, 3 blur y, 4 z derivative, 5 slice + modify."""
+Slots: 8 set-up (sample window + table records), 0 its barrier, 1 splat, 2 blur x, 3 blur y, 4 z derivative, 5 slice + modify."""
 import ctypes as C
 import json
 import sys

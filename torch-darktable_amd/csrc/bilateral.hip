@@ -377,20 +377,6 @@ __global__ __launch_bounds__(64) void bilateral_axis_tables_kernel(int* __restri
   if (lane == 0) { rec[0] = t.c_lo; rec[1] = t.nc; rec[2] = nmax; }
 }
 
-// x / c for a divisor c that is constant over the launch, rc = 1.0f / c (correctly rounded, host):
-// q = RN(x * rc), r = x - q * c exactly (fma), q' = RN(q + r * rc) is the correctly rounded
-// quotient (Markstein) as long as nothing under- or overflows -- 3 instructions instead of the
-// ~12 of v_div_scale / v_rcp / Newton / v_div_fixup.  Outside the safe range: the real division.
-__device__ __forceinline__ float div_by(float x, float c, float rc) {
-  const float ax = fabsf(x);
-  const bool safe = (ax >= 0x1p-40f && ax <= 0x1p40f) || x == 0.0f;
-  // wave-uniform test so that the compiler keeps a real (never taken) branch instead of computing both
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(safe && c >= 0x1p-20f && c <= 0x1p20f)) != 0, 0)) return x / c;
-  const float q = x * rc;
-  const float r = __builtin_fmaf(-q, c, x);
-  return __builtin_fmaf(r, rc, q);
-}
-
 // i / n for 0 <= i < 2^20, 0 < n < 2^10 with inv = 1.0f / n: (i + 0.5) / n is at least 0.5 / n away
 // from an integer, far more than the float rounding error, so the truncation is exact.
 __device__ __forceinline__ int fast_div(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
@@ -429,7 +415,11 @@ __device__ __forceinline__ void splat_column(float* __restrict__ acc, const floa
   }
 }
 
-// gz = clamp(L / sigma_r, 0, ztop) of N samples: the exact-quotient shortcut of div_by with ONE range test for all N
+// gz = clamp(L / sigma_r, 0, ztop) of N samples.  x / c for a divisor c that is constant over the launch, rc = 1.0f / c
+// (correctly rounded, host): q = RN(x * rc), r = x - q * c exactly (fma), q' = RN(q + r * rc) is the correctly rounded quotient
+// (Markstein) as long as nothing under- or overflows -- 3 instructions instead of the ~12 of v_div_scale / v_rcp / Newton /
+// v_div_fixup; ONE range test covers all N samples (wave-uniform, so that the compiler keeps a real, never taken branch to
+// the plain division instead of computing both).
 template <int N>
 __device__ __forceinline__ void sample_gz(const float (&v)[N], float (&g)[N], float sigma_r, float rc_r, float ztop) {
   float hi = fabsf(v[0]);
