@@ -64,6 +64,29 @@ def test_rcd_12mp_right_and_bottom_edges(td, oracle, dev, frame12):
     assert np.array_equal(got, oracle.rcd(npy(strip), oracle.RGGB))
 
 
+@pytest.mark.parametrize('shape', [(W12, H12), (W50, H50), (4096 + 2, 3072 - 31)])
+def test_rcd_strips_equal_tiles_on_whole_frames(td, dev, shape):
+    """The column strips (csrc/tdk_rcd_stream.h) and the 64 x 64 tile kernel must agree on EVERY pixel of a full-size frame --
+    all strip and segment seams, the moved-back last strip / segment, the border rules on all four sides and the ring -- for
+    fp32 and fp16 storage and a second CFA phase.  (The windows above tie the result to the oracle.)"""
+    from torch_darktable._native import lib
+    from torch_darktable.synthetic import synthetic_bayer
+
+    w, h = shape
+    bayer = synthetic_bayer(h, w, seed=77, device=dev)
+    for pattern in (td.BayerPattern.RGGB, td.BayerPattern.GBRG):
+        ws = td.RCD(dev, (w, h), pattern)
+        for x in (bayer, bayer.half()):
+            strips = ws.process(x)
+            assert lib.tdk_rcd_select_path(1) == 0
+            try:
+                tiles = ws.process(x)
+            finally:
+                assert lib.tdk_rcd_select_path(0) == 0
+            assert torch.equal(strips, tiles), f'{shape} {pattern} {x.dtype}: {(strips != tiles).sum().item()} values differ'
+            del strips, tiles
+
+
 def test_ppg_bilinear_12mp_crop_consistency(td, oracle, dev, frame12):
     ppg = td.PPG(dev, (W12, H12), td.BayerPattern.RGGB).process(frame12)
     bil = td.bilinear5x5_demosaic(frame12, td.BayerPattern.RGGB)
