@@ -141,6 +141,28 @@ def test_rcd_strips_equal_tiles(td, oracle, dev, scene, pattern, size):
         assert bad.size == 0, f'{name}: {len(bad)} mismatches, first at {bad[:5].tolist()}'
 
 
+def test_rcd_strips_equal_tiles_on_many_geometries(td, dev):
+    """Strip / segment geometry sweep: widths around the multiples of the 108-column strip (one strip exactly, a last strip
+    moved back by 2 .. 106 columns), heights around the segment rules (64 = the minimum, odd, one row more than a multiple of
+    the 8-row step), all against the tile kernel (itself tied to the oracle above) on every pixel."""
+    from torch_darktable._native import lib
+    rng = np.random.default_rng(2024)
+    widths = [128, 130, 214, 216, 218, 234, 322, 324, 326, 1000]
+    heights = [64, 65, 71, 72, 73, 127, 128, 129, 200, 333]
+    cases = [(w, h) for w, h in zip(widths, heights)] + [(int(rng.integers(64, 400)) * 2, int(rng.integers(64, 500))) for _ in range(10)]
+    for w, h in cases:
+        bayer = torch.from_numpy(rng.random((h, w, 1), dtype=np.float32)).to(dev)
+        pattern = [td.BayerPattern.RGGB, td.BayerPattern.BGGR, td.BayerPattern.GRBG, td.BayerPattern.GBRG][(w // 2 + h) % 4]
+        ws = td.RCD(dev, (w, h), pattern)
+        strips = ws.process(bayer)
+        assert lib.tdk_rcd_select_path(1) == 0
+        try:
+            tiles = ws.process(bayer)
+        finally:
+            assert lib.tdk_rcd_select_path(0) == 0
+        assert torch.equal(strips, tiles), f'{w}x{h} {pattern}: {(strips != tiles).sum().item()} values differ'
+
+
 @pytest.mark.parametrize('size', [(2, 2), (2, 4), (4, 4), (4, 6), (6, 8), (10, 14), (14, 16), (16, 16), (7, 5), (3, 64), (64, 2)])
 def test_tiny_images_every_stencil_op(td, oracle, dev, size):
     """Images smaller than every halo / tile / ring: all pixels are border cases (the oracle was run
