@@ -449,6 +449,28 @@ def test_bilateral_tile_kernel(td, oracle, dev, scene, sig, size):
         assert lib.tdk_bilateral_select_path(0) == 0
 
 
+def test_bilateral_tile_kernel_geometry_sweep(td, dev):
+    """The tile kernel's per-launch axis tables and fixed sample window over many frame sizes and sigmas (tile counts that end
+    in partial tiles on either axis, widths that are / are not multiples of 4, sigma_s from 1 to 4 with non-integer values,
+    short and long z columns): the tile path must equal the four-kernel path bit for bit, for planes and the RGB epilogue."""
+    from torch_darktable._native import lib
+    rng = np.random.default_rng(99)
+    cases = [(64, 32, 2.0, 0.2), (65, 33, 2.0, 0.2), (128, 64, 1.5, 0.25), (130, 70, 4.0, 0.1), (67, 200, 3.3, 0.05), (400, 37, 1.0, 0.25), (36, 40, 2.7, 0.02)]
+    cases += [(int(rng.integers(40, 500)), int(rng.integers(40, 300)), float(rng.uniform(1.0, 4.0)), float(rng.choice([0.02, 0.07, 0.1, 0.2, 0.25]))) for _ in range(12)]
+    for w, h, ss, sr in cases:
+        lum = torch.from_numpy(rng.random((h, w), dtype=np.float32)).to(dev)
+        rgb = torch.from_numpy(rng.random((h, w, 3), dtype=np.float32)).to(dev)
+        ws = td.Bilateral(dev, (w, h), sigma_s=ss, sigma_r=sr)
+        a, a16, argb = ws.process(lum, 0.4), ws.process(lum.half(), 0.4), ws.process_rgb(rgb, 0.4)
+        assert lib.tdk_bilateral_select_path(1) == 0
+        try:
+            b, b16, brgb = ws.process(lum, 0.4), ws.process(lum.half(), 0.4), ws.process_rgb(rgb, 0.4)
+        finally:
+            assert lib.tdk_bilateral_select_path(0) == 0
+        for name, x, y in (('plane', a, b), ('plane f16', a16, b16), ('rgb', argb, brgb)):
+            assert torch.equal(x, y), f'{w}x{h} sigma ({ss:.3f}, {sr}) {name}: {(x != y).sum().item()} values differ'
+
+
 @pytest.mark.parametrize('K,ov', [(32, 4), (32, 2), (16, 4), (16, 8), (32, 8), (16, 2)])
 @pytest.mark.parametrize('C', [1, 3])
 def test_wiener(td, oracle, dev, scene, K, ov, C):
