@@ -1,4 +1,4 @@
-// tdk_rcd_stream.h -- RCD for the part of the image that keeps clear of every border rule: column strips walked downwards.
+// tdk_rcd_stream.h -- RCD as column strips walked down the frame (every frame of at least 128 x 64 whose rows load as sample pairs).
 // Included by rcd.hip inside its anonymous namespace (shares div_pos / div_signed, Range, CFA_MIN / CFA_MAX).
 //
 // Same nine steps and the same expressions as rcd_phases (reference csrc/debayer/rcd.cu:63-282); what changes is the order in
@@ -18,7 +18,8 @@
 // handles both columns of its pair in the full-density steps and the one R/B (or green) site of the pair otherwise.
 // A strip is cut into vertical segments (one workgroup each, 10 + 10 rows of warm-up / drain overlap) so that the launch
 // fills the chip.  The strips cover the whole frame: sites outside a step's border range hold 0 (Cols / Rows below), the
-// [0, 7) ring is border_pixel's (a share per workgroup).  rcd_phases (rcd_interior) keeps the frames the strips do not fit.
+// [0, 7) ring is staged in pieces by the same workgroups (ring_piece in rcd.hip).  rcd_phases (rcd_interior) keeps the frames
+// the strips do not fit.
 #pragma once
 
 namespace rs {
