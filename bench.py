@@ -494,6 +494,8 @@ def main(argv=None):
             # the same kernel with the GPU to itself (untimed serial pass): in the timed region frames on the other stream(s) share the CUs with it
             'avg_launch_us_alone': round(alone_s * 1e6, 2),
             'hbm_frac_alone': round(lbpp * w * h / alone_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None,
+            'frac_alone': (round(valu['alu_floor_us'] * 1e-6 / alone_s, 4) if bound == 'valu'
+                           else (round(lbpp * w * h / alone_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None)),
             'kernel_launches_in_timed_region': launches_total, 'valu': valu, 'composite': composite,
         }
     # whole-pipeline roofline at the Python-wrapper stage boundaries (41 B/px f16, 79 B/px f32; RCD only: 4*s B/px)
