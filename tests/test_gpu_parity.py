@@ -469,6 +469,23 @@ def test_bilateral_tile_kernel_geometry_sweep(td, dev):
             assert lib.tdk_bilateral_select_path(0) == 0
         for name, x, y in (('plane', a, b), ('plane f16', a16, b16), ('rgb', argb, brgb)):
             assert torch.equal(x, y), f'{w}x{h} sigma ({ss:.3f}, {sr}) {name}: {(x != y).sum().item()} values differ'
+    # samples outside the range of the exact-quotient shortcut (zeros, denormals, huge, negative, inf, nan): the tile kernel's
+    # grouped range test must fall back to the plain division exactly where the general path divides
+    w, h = 256, 96
+    lum = rng.random((h, w), dtype=np.float32)
+    special = np.array([0.0, -0.0, 1e-45, 1e-39, 2.0 ** -41, 2.0 ** -40, 2.0 ** 40, 2.0 ** 41, 1e30, -0.3, -1e30, np.inf, -np.inf, np.nan], np.float32)
+    ys, xs = rng.integers(0, h, 200), rng.integers(0, w, 200)
+    lum[ys, xs] = special[rng.integers(0, len(special), 200)]
+    lum_t = torch.from_numpy(lum).to(dev)
+    ws = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
+    a = ws.process(lum_t, 0.4)
+    assert lib.tdk_bilateral_select_path(1) == 0
+    try:
+        b = ws.process(lum_t, 0.4)
+    finally:
+        assert lib.tdk_bilateral_select_path(0) == 0
+    same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    assert bool(same.all()), f'special values: {(~same).sum().item()} values differ'
 
 
 @pytest.mark.parametrize('K,ov', [(32, 4), (32, 2), (16, 4), (16, 8), (32, 8), (16, 2)])
