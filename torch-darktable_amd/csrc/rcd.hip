@@ -77,12 +77,14 @@ template <bool FAST> __device__ __forceinline__ float div_pos(float a, float b) 
   else return a / b;
 }
 
-template <bool FAST, int N> __device__ __forceinline__ void div_signed(const float (&a)[N], const float (&b)[N], float (&q)[N]) {
+// `lanes`: the lanes whose quotients anything reads (a 64-bit lane mask); the others may hold garbage on either path and do
+// not count in the wave's test.
+template <bool FAST, int N> __device__ __forceinline__ void div_signed(const float (&a)[N], const float (&b)[N], float (&q)[N], unsigned long long lanes = ~0ull) {
   if constexpr (FAST) {
     float mn = fabsf(a[0]);
 #pragma unroll
     for (int i = 1; i < N; i++) mn = fminf(mn, fabsf(a[i]));
-    if (__builtin_amdgcn_ballot_w64(!(mn >= tdk::DIV_CORE_MIN_NUM)) == 0) {
+    if ((__builtin_amdgcn_ballot_w64(!(mn >= tdk::DIV_CORE_MIN_NUM)) & lanes) == 0) {
 #pragma unroll
       for (int i = 0; i < N; i++) q[i] = tdk::div_core(a[i], b[i]);
       return;

@@ -70,6 +70,14 @@ constexpr int slide_slots() {
 constexpr int SLIDE_SLOTS = slide_slots();  // 1152
 static_assert(SLIDE_SLOTS <= 3 * NT, "three slots per thread");
 
+// A slide slot as one 16-byte LDS access.  hipcc takes the alignment of an access to `extern __shared__ float lds[]` from
+// that declaration (4 bytes), whatever the pointer is cast to, and splits a float4 into two ds_read2_b32 / ds_write2_b32 whose
+// lanes are 16 bytes apart: a 4-way bank conflict on every one of them (a quarter of this kernel's LDS cycles in round 3's
+// counters).  Every plane base and row length is a multiple of 4 floats and the dynamic LDS base is 16-byte aligned (no
+// static __shared__ in this kernel), so the promise below holds and the slide moves as ds_read_b128 / ds_write_b128.
+__device__ __forceinline__ float4* slot16(float* p) { return reinterpret_cast<float4*>(__builtin_assume_aligned(p, 16)); }
+static_assert(PAD % 4 == 0, "plane bases are multiples of 4 floats");
+
 // destination offset (floats) of slide slot k and the distance to its source; dst < 0: no slot
 __device__ __forceinline__ void slide_slot(int k, int& dst, int& dist) {
   dst = -1; dist = 0;
@@ -83,24 +91,45 @@ __device__ __forceinline__ void slide_slot(int k, int& dst, int& dist) {
 }
 
 // Border rules (the `row/col >= k && <= size - k` ranges of rcd.cu's kernels): a site outside a step's range holds 0, as in the
-// reference's zero-initialised planes.  Column tests per lane and column parity, computed once per thread (the compiler keeps
-// them as lane masks in SGPRs); row tests are wave-uniform and made per step.
+// reference's zero-initialised planes.  The column tests are made once per thread and kept as 64-bit LANE MASKS (wave-uniform
+// values: SGPR pairs), the row tests are wave-uniform and made per step; a site's rule is `row ? cols : 0`, scalar work.
+// The select that applies it is written as VOP3 v_cndmask with the SGPR pair as its mask operand (keep()): left to hipcc, a
+// mask that the scalar unit produced is copied to VCC for the short VOP2 form -- and a VOP2 v_cndmask reading a VCC that the
+// SALU wrote costs ~23 SIMD cycles on gfx950 instead of ~4.4 (tests/hip_unit/select_bench.hip, profiles/r04/select_bench.txt);
+// round 3's strips carried about fifteen of those per step.
+using lmask = unsigned long long;
 struct Cols {
-  bool c3[2];   // [3, w - 4]   steps 1.1, 4.1
-  bool c2a[2];  // [2, w - 3]   steps 1.2, 4.2
-  bool c2b[2];  // [2, w - 2]   step 2.1
-  bool c4a[2];  // [4, w - 5]   step 3.1
-  bool c4b[2];  // [4, w - 4]   step 5.1
-  bool img;     // the pair lies inside the frame
-  bool o7[2];   // [7, w - 7) and one of the strip's own columns: the pixel is stored
+  lmask c3[2];   // [3, w - 4]   steps 1.1, 4.1
+  lmask c2a[2];  // [2, w - 3]   steps 1.2, 4.2
+  lmask c2b[2];  // [2, w - 2]   step 2.1
+  lmask c4a[2];  // [4, w - 5]   step 3.1
+  lmask c4b[2];  // [4, w - 4]   step 5.1
+  lmask img;     // the pair lies inside the frame
+  bool o7[2];    // [7, w - 7) and one of the strip's own columns: the pixel is stored (per lane: it guards stores)
 };
 struct Rows {  // of the current block, for this wave
   bool r21, r11, r12, r31, r51, rimg41, rout;
 };
+__device__ __forceinline__ lmask rule(bool row_ok, lmask cols) { return row_ok ? cols : 0ull; }
+// v where the lane's bit of m is set, +0 elsewhere
+__device__ __forceinline__ float keep(lmask m, float v) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  return r;
+}
+
+// The three code variants of a step (MODE):
+//   SLOW   every border rule, IEEE divisions: blocks whose 24 newest CFA rows fail the range check of the exact fast division
+//   FASTM  every border rule, the exact fast division (tdk_fastdiv.h) except in step 4.2: border blocks with samples in range
+//   INNER  no border rule at all and the fast division everywhere: blocks whose window keeps clear of every `>= k, <= size - k`
+//          range of the nine steps (columns [gx0, gx0 + 128) inside [4, w - 5], the rows of all lags inside [4, h - 5]) and
+//          therefore also of every stale p/q slot (columns 1, w - 3, w - 1, rows < 3 or > h - 4: step 4.1).  At 12 MP that is
+//          36 of the 38 strips and all but the first / last two blocks of a strip's first / last segment.
+constexpr int SLOW = 0, FASTM = 1, INNER = 2;
 
 // One step of one wave.  PE = column parity of the R/B sites in this wave's rows of the EVEN-lag steps (odd-lag steps see the
 // other parity: consecutive rows alternate).  b128 / b64: LDS + w * 128 + l / LDS + w * 64 + l.
-template <bool FAST, int PE, typename TI>
+template <int MODE, int PE, typename TI>
 __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv, const TI* __restrict__ in,
                                                  int gx_odd, int gy41, int w, int h) {
   // ---- step 2.1 (lag 1): lpf at the R/B site of the pair
@@ -108,7 +137,7 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
     constexpr int L = LAG_21, p = PE ^ (L & 1);
     auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
     const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
-    b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = (rv.r21 && cv.c2b[p]) ? v : 0.0f;
+    b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = MODE == INNER ? v : keep(rule(rv.r21, cv.c2b[p]), v);
   }
   // ---- step 1.1 (lag 3): v_diff / h_diff at both columns
   {
@@ -118,9 +147,9 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
       auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
       const float vd = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
       const float hd = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
-      const bool ok = rv.r11 && cv.c3[p];
-      b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = ok ? vd : 0.0f;
-      b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = ok ? hd : 0.0f;
+      const lmask ok = rule(rv.r11, cv.c3[p]);
+      b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = MODE == INNER ? vd : keep(ok, vd);
+      b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = MODE == INNER ? hd : keep(ok, hd);
     }
   }
   // ---- step 4.1 (lag 3): p/q_diff at the odd column
@@ -130,18 +159,22 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
     const float pd = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
     const float qd = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
     float pv = pd, qv = qd;
-    // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
-    // rcd.hip); outside the frame: 0
-    const bool inside = rv.rimg41 && cv.img, ranged = rv.r11 && cv.c3[1];
-    if (__builtin_amdgcn_ballot_w64(inside && !ranged) != 0) {
-      if (inside && !ranged) { pv = stale_diff(in, gy41, gx_odd, w, h, true); qv = stale_diff(in, gy41, gx_odd, w, h, false); }
+    if constexpr (MODE != INNER) {
+      // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
+      // rcd.hip); outside the frame: 0
+      const lmask inside = rule(rv.rimg41, cv.img), stale = inside & ~rule(rv.r11, cv.c3[1]);
+      if (stale != 0) {
+        if ((stale >> (threadIdx.x & 63)) & 1) { pv = stale_diff(in, gy41, gx_odd, w, h, true); qv = stale_diff(in, gy41, gx_odd, w, h, false); }
+      }
+      pv = keep(inside, pv);
+      qv = keep(inside, qv);
     }
-    b64[h64<P_B, P_L, P_W>(L, 0, 0)] = inside ? pv : 0.0f;
-    b64[h64<Q_B, Q_L, Q_W>(L, 0, 0)] = inside ? qv : 0.0f;
+    b64[h64<P_B, P_L, P_W>(L, 0, 0)] = pv;
+    b64[h64<Q_B, Q_L, Q_W>(L, 0, 0)] = qv;
   }
 }
 
-template <bool FAST, int PE>
+template <int MODE, int PE>
 __device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv) {
   // ---- step 1.2 (lag 4): VH_dir at both columns
   {
@@ -153,7 +186,8 @@ __device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __
       const float eps = 1e-10f;
       const float V_Stat = fmaxf(eps, vd(-1) + vd(0) + vd(1));
       const float H_Stat = fmaxf(eps, hd(-1) + hd(0) + hd(1));
-      b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = (rv.r12 && cv.c2a[p]) ? div_pos<FAST>(V_Stat, V_Stat + H_Stat) : 0.0f;
+      const float vh = div_pos<MODE != SLOW>(V_Stat, V_Stat + H_Stat);
+      b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = MODE == INNER ? vh : keep(rule(rv.r12, cv.c2a[p]), vh);
     }
   }
   // ---- step 4.2 (lag 4): PQ_dir at the R/B site (column 2 l + p).  p/q slot of odd column 2 j + 1 = entry j; the slots of
@@ -165,13 +199,14 @@ __device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __
     const float eps = 1e-10f;
     const float P_Stat = fmaxf(eps, P(-1, jm) + P(0, 0) + P(1, jm + 1));
     const float Q_Stat = fmaxf(eps, Q(-1, jm + 1) + Q(0, 0) + Q(1, jm));
-    // plain division: a stale slot (see step 4.1) can hold values of samples no range check has seen
-    b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = (rv.r12 && cv.c2a[p]) ? P_Stat / (P_Stat + Q_Stat) : 0.0f;
+    // plain division wherever a stale slot (see step 4.1) can be near: it holds values of samples no range check has seen
+    const float pq = div_pos<MODE == INNER>(P_Stat, P_Stat + Q_Stat);
+    b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = MODE == INNER ? pq : keep(rule(rv.r12, cv.c2a[p]), pq);
   }
 }
 
 // ---- step 3.1 (lag 5): green at the R/B site
-template <bool FAST, int PE>
+template <int MODE, int PE>
 __device__ __forceinline__ void step_3_1(float* __restrict__ b128, float* __restrict__ b64, const Cols& cv, const Rows& rv) {
   constexpr int L = LAG_31, p = PE ^ (L & 1);
   auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
@@ -187,19 +222,20 @@ __device__ __forceinline__ void step_3_1(float* __restrict__ b128, float* __rest
   const float W_Grad = eps + fabsf(a(0, -1) - a(0, 1)) + fabsf(cfai - a(0, -2)) + fabsf(a(0, -1) - a(0, -3)) + fabsf(a(0, -2) - a(0, -4));
   const float E_Grad = eps + fabsf(a(0, 1) - a(0, -1)) + fabsf(cfai - a(0, 2)) + fabsf(a(0, 1) - a(0, 3)) + fabsf(a(0, 2) - a(0, 4));
   const float lpfi = lp(0, 0);
-  const float N_Est = div_pos<FAST>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
-  const float S_Est = div_pos<FAST>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
-  const float W_Est = div_pos<FAST>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
-  const float E_Est = div_pos<FAST>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
-  const float V_Est = div_pos<FAST>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
-  const float H_Est = div_pos<FAST>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
-  b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = (rv.r31 && cv.c4a[p]) ? mixf(V_Est, H_Est, VH_Disc) : 0.0f;
+  const float N_Est = div_pos<MODE != SLOW>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
+  const float S_Est = div_pos<MODE != SLOW>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
+  const float W_Est = div_pos<MODE != SLOW>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
+  const float E_Est = div_pos<MODE != SLOW>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
+  const float V_Est = div_pos<MODE != SLOW>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
+  const float H_Est = div_pos<MODE != SLOW>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
+  const float grn = mixf(V_Est, H_Est, VH_Disc);
+  b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = MODE == INNER ? grn : keep(rule(rv.r31, cv.c4a[p]), grn);
 }
 
 // ---- step 5.1 (lag 7): the opposite colour at the R/B site.  `lanes_ok`: lanes whose numerators count in the wave's
-// fast-division test (the outermost columns compute on garbage).
-template <bool FAST, int PE>
-__device__ __forceinline__ void step_5_1(float* __restrict__ b128, float* __restrict__ b64, bool lanes_ok, const Cols& cv, const Rows& rv) {
+// fast-division test (the outermost columns compute on garbage, which nothing that is stored ever reads).
+template <int MODE, int PE>
+__device__ __forceinline__ void step_5_1(float* __restrict__ b128, float* __restrict__ b64, lmask lanes_ok, const Cols& cv, const Rows& rv) {
   constexpr int L = LAG_51, p = PE ^ (L & 1);
   auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
   auto pq = [&](int dr, int sh) { return b64[h64<PQ_B, PQ_L, PQ_W>(L, dr, sh)]; };
@@ -222,18 +258,18 @@ __device__ __forceinline__ void step_5_1(float* __restrict__ b128, float* __rest
   const float SE_Est = a(1, 1) - G(1, 1);
   float num[2] = {NW_Grad * SE_Est + SE_Grad * NW_Est, NE_Grad * SW_Est + SW_Grad * NE_Est};
   float den[2] = {NW_Grad + SE_Grad, NE_Grad + SW_Grad};
-  const bool ok = rv.r51 && cv.c4b[p];
-  if (!(lanes_ok && ok)) { num[0] = num[1] = 1.0f; den[0] = den[1] = 1.0f; }
+  const lmask ok = MODE == INNER ? ~0ull : rule(rv.r51, cv.c4b[p]);
   float est[2];  // P_Est, Q_Est
-  div_signed<FAST>(num, den, est);
-  b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = ok ? g0 + mixf(est[0], est[1], PQ_Disc) : 0.0f;
+  div_signed<MODE != SLOW>(num, den, est, lanes_ok & ok);
+  const float colv = g0 + mixf(est[0], est[1], PQ_Disc);
+  b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = MODE == INNER ? colv : keep(ok, colv);
 }
 
 // ---- step 5.2 (lag 10) at the green site of the pair + the two finished pixels of the pair
-template <bool FAST, int PE, typename T>
+template <int MODE, int PE, typename T>
 __device__ __forceinline__ void step_5_2_out(float* __restrict__ b128, float* __restrict__ b64, bool red_row, T* __restrict__ dst, const Cols& cv, const Rows& rv) {
   const bool st_e = rv.rout && cv.o7[0], st_o = rv.rout && cv.o7[1];  // column 2 l / 2 l + 1 is stored
-  const bool lanes_ok = st_e || st_o;
+  const lmask lanes_ok = __builtin_amdgcn_ballot_w64(st_e || st_o);
   constexpr int L = LAG_52, p = PE ^ (L & 1), pg = 1 - p;  // R/B sites on parity p, the green site of the pair on pg
   auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, pg, dc)]; };
   auto vh = [&](int dr, int dc) { return b128[f128<VH_B, VH_L, VH_W>(L, dr, pg, dc)]; };
@@ -278,32 +314,32 @@ __device__ __forceinline__ void step_5_2_out(float* __restrict__ b128, float* __
     num[2 * ci + 1] = E_Grad * W_Est + W_Grad * E_Est;
     den[2 * ci + 1] = E_Grad + W_Grad;
   }
-  if (!lanes_ok) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) { num[i] = 1.0f; den[i] = 1.0f; }
-  }
-  div_signed<FAST>(num, den, est);
+  div_signed<MODE != SLOW>(num, den, est, lanes_ok);
   const float own = fmaxf(g + mixf(est[0], est[1], VH_Disc), 0.0f), oth = fmaxf(g + mixf(est[2], est[3], VH_Disc), 0.0f);
-  float gpx[3] = {red_row ? own : oth, fmaxf(g, 0.0f), red_row ? oth : own};
   // the R/B pixel of the pair: native, green from step 3.1, other colour from step 5.1
   const float native = fmaxf(b128[f128<CFA_B, CFA_L, CFA_W>(L, 0, p, 0)], 0.0f), green = fmaxf(grn(0, 0), 0.0f), other = fmaxf(col(0, 0), 0.0f);
-  float rbpx[3] = {red_row ? native : other, green, red_row ? other : native};
-  // column 2 l first: the R/B pixel when the R/B sites of this row sit on even columns
-  const float f0 = p == 0 ? rbpx[0] : gpx[0], f1 = p == 0 ? rbpx[1] : gpx[1], f2 = p == 0 ? rbpx[2] : gpx[2];
-  const float s0 = p == 0 ? gpx[0] : rbpx[0], s1 = p == 0 ? gpx[1] : rbpx[1], s2 = p == 0 ? gpx[2] : rbpx[2];
-  if (st_e && st_o) {
-    if constexpr (sizeof(T) == 4) {
-      struct alignas(8) px6 { float a, b, c, d, e, f; };
-      *reinterpret_cast<px6*>(dst) = px6{f0, f1, f2, s0, s1, s2};
-    } else {
-      struct alignas(4) pair6 { __half2 a, b, c; };
-      *reinterpret_cast<pair6*>(dst) = pair6{__floats2half2_rn(f0, f1), __floats2half2_rn(f2, s0), __floats2half2_rn(s1, s2)};
+  const float gg = fmaxf(g, 0.0f);
+  // {R, G, B} of the green pixel and of the R/B pixel; red_row is wave-uniform: a branch, not six selects
+  auto store = [&](float gr, float gb, float rr, float rb) {
+    // column 2 l first: the R/B pixel when the R/B sites of this row sit on even columns
+    const float f0 = p == 0 ? rr : gr, f1 = p == 0 ? green : gg, f2 = p == 0 ? rb : gb;
+    const float s0 = p == 0 ? gr : rr, s1 = p == 0 ? gg : green, s2 = p == 0 ? gb : rb;
+    if (st_e && st_o) {
+      if constexpr (sizeof(T) == 4) {
+        struct alignas(8) px6 { float a, b, c, d, e, f; };
+        *reinterpret_cast<px6*>(dst) = px6{f0, f1, f2, s0, s1, s2};
+      } else {
+        struct alignas(4) pair6 { __half2 a, b, c; };
+        *reinterpret_cast<pair6*>(dst) = pair6{__floats2half2_rn(f0, f1), __floats2half2_rn(f2, s0), __floats2half2_rn(s1, s2)};
+      }
+    } else if (st_e) {  // the frame's last stored column is even (w - 8) ...
+      st(dst, 0, f0); st(dst, 1, f1); st(dst, 2, f2);
+    } else if (st_o) {  // ... its first one odd (7)
+      st(dst, 3, s0); st(dst, 4, s1); st(dst, 5, s2);
     }
-  } else if (st_e) {  // the frame's last stored column is even (w - 8) ...
-    st(dst, 0, f0); st(dst, 1, f1); st(dst, 2, f2);
-  } else if (st_o) {  // ... its first one odd (7)
-    st(dst, 3, s0); st(dst, 4, s1); st(dst, 5, s2);
-  }
+  };
+  if (red_row) store(own, oth, native, other);
+  else store(oth, own, other, native);
 }
 
 template <typename TI> struct Pair;
@@ -331,7 +367,9 @@ template <typename TI, typename T>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void rcd_stream(const TI* __restrict__ in, T* __restrict__ out, int w, int h,
                                                                                               uint32_t pattern, int nstrips, int seg_rows, int nbx, int nby) {
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+  // the wave number through readfirstlane: everything derived from it (the row rules above all) is then scalar work for the
+  // compiler, which cannot prove threadIdx.x >> 6 wave-uniform
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
   // the [0, 7) border ring (independent of the strips: disjoint output pixels, input read-only): one piece per workgroup until
   // the pieces run out, staged through the plane area
   for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
   const int pe = ((gy0 + wv) & 1) ? rowpar1 : rowpar0;
   // colour of the R/B sites in this wave's output rows (lag 10: even)
   const bool red_row = cfa_color(gy0 + wv, pe, pattern) == 0;
-  const bool lanes_51 = l >= 3 && l < 61;  // the pairs whose step-5.1 colour a stored pixel can read (3 columns away)
+  const lmask lanes_51 = __builtin_amdgcn_ballot_w64(l >= 3 && l < 61);  // the pairs whose step-5.1 colour a stored pixel can read (3 columns away)
   const bool own = l >= HALO / 2 && l < (HALO + TWS) / 2;  // the strip's own pairs
 
   Cols cv;
@@ -361,14 +399,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #pragma unroll
   for (int p = 0; p < 2; p++) {
     const int gx = gxe + p;
-    cv.c3[p] = gx >= 3 && gx <= w - 4;
-    cv.c2a[p] = gx >= 2 && gx <= w - 3;
-    cv.c2b[p] = gx >= 2 && gx <= w - 2;
-    cv.c4a[p] = gx >= 4 && gx <= w - 5;
-    cv.c4b[p] = gx >= 4 && gx <= w - 4;
+    cv.c3[p] = __builtin_amdgcn_ballot_w64(gx >= 3 && gx <= w - 4);
+    cv.c2a[p] = __builtin_amdgcn_ballot_w64(gx >= 2 && gx <= w - 3);
+    cv.c2b[p] = __builtin_amdgcn_ballot_w64(gx >= 2 && gx <= w - 2);
+    cv.c4a[p] = __builtin_amdgcn_ballot_w64(gx >= 4 && gx <= w - 5);
+    cv.c4b[p] = __builtin_amdgcn_ballot_w64(gx >= 4 && gx <= w - 4);
     cv.o7[p] = own && gx >= 7 && gx < w - 7;
   }
-  cv.img = gxe >= 0 && gxe < w;  // w even: a pair is inside or outside as a whole
+  const bool pair_in = gxe >= 0 && gxe < w;  // w even: a pair is inside or outside as a whole
+  cv.img = __builtin_amdgcn_ballot_w64(pair_in);
+  // every column of the window inside every step's column range (and clear of the stale p/q slots): workgroup-uniform
+  const bool inner_cols = gx0 >= 4 && gx0 + 127 <= w - 5;
 
   // slide slots of this thread
   int sd[3], sdist[3];
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
   bool st_in = false;
   auto prefetch = [&](int b) {
     const int gy = gy0 + RB * b + wv;
-    st_in = cv.img && gy >= 0 && gy < h;
+    st_in = pair_in && gy >= 0 && gy < h;
     if (st_in) st.fetch(in + (size_t)gy * w + gxe);
   };
   prefetch(0);
@@ -391,14 +432,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
   for (int b = 0; b < nsteps; b++) {
     // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
     if (b > 0) {
-      const float4 s0 = *reinterpret_cast<const float4*>(lds + sd[0] + sdist[0]);
-      const float4 s1 = *reinterpret_cast<const float4*>(lds + sd[1] + sdist[1]);
+      const float4 s0 = *slot16(lds + sd[0] + sdist[0]);
+      const float4 s1 = *slot16(lds + sd[1] + sdist[1]);
       float4 s2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (third) s2 = *reinterpret_cast<const float4*>(lds + sd[2] + sdist[2]);
+      if (third) s2 = *slot16(lds + sd[2] + sdist[2]);
       wg_barrier();
-      *reinterpret_cast<float4*>(lds + sd[0]) = s0;
-      *reinterpret_cast<float4*>(lds + sd[1]) = s1;
-      if (third) *reinterpret_cast<float4*>(lds + sd[2]) = s2;
+      *slot16(lds + sd[0]) = s0;
+      *slot16(lds + sd[1]) = s1;
+      if (third) *slot16(lds + sd[2]) = s2;
     }
     // ---- the new CFA rows (max(0, in)), their range verdict, and the next block's samples on their way
     {
@@ -424,6 +465,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
     const bool fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
     ok2 = ok1; ok1 = ok0;
+    // the rows of every step of this block (lags 1 .. 10 behind rows gy0 + 8 b .. + 7) inside every step's row range
+    const bool inner = inner_cols && gy0 + RB * b - LAG_52 >= 4 && gy0 + RB * b + RB - 1 - LAG_21 <= h - 5;
 
     // frame rows of this wave's sites in the steps of this block, and their border rules
     const int gyb = gy0 + RB * b + wv;  // row of lag 0
@@ -437,21 +480,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     rv.rout = orow >= HALO && orow < HALO + seg_rows && gyo >= 7 && gyo < h - 7;
     T* dst = out + ((size_t)gyo * w + gxe) * 3;
 
-#define RS_STEP(FASTV, PEV)                                                                                \
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RS_NO_PHASE_BARRIERS)  // timing experiment only (wrong results): what the four barriers between the steps cost
+#define RS_PHASE_BARRIER() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local")
+#else
+#define RS_PHASE_BARRIER() wg_barrier()
+#endif
+#define RS_STEP(MODEV, PEV)                                                                                \
   do {                                                                                                     \
-    step_2_1_1_1_4_1<FASTV, PEV, TI>(b128, b64, cv, rv, in, gxe + 1, gyb - LAG_41, w, h);                  \
-    wg_barrier();                                                                                          \
-    step_1_2_4_2<FASTV, PEV>(b128, b64, cv, rv);                                                           \
-    wg_barrier();                                                                                          \
-    step_3_1<FASTV, PEV>(b128, b64, cv, rv);                                                               \
-    wg_barrier();                                                                                          \
-    step_5_1<FASTV, PEV>(b128, b64, lanes_51, cv, rv);                                                     \
-    wg_barrier();                                                                                          \
-    step_5_2_out<FASTV, PEV, T>(b128, b64, red_row, dst, cv, rv);                                          \
+    step_2_1_1_1_4_1<MODEV, PEV, TI>(b128, b64, cv, rv, in, gxe + 1, gyb - LAG_41, w, h);                  \
+    RS_PHASE_BARRIER();                                                                                    \
+    step_1_2_4_2<MODEV, PEV>(b128, b64, cv, rv);                                                           \
+    RS_PHASE_BARRIER();                                                                                    \
+    step_3_1<MODEV, PEV>(b128, b64, cv, rv);                                                               \
+    RS_PHASE_BARRIER();                                                                                    \
+    step_5_1<MODEV, PEV>(b128, b64, lanes_51, cv, rv);                                                     \
+    RS_PHASE_BARRIER();                                                                                    \
+    step_5_2_out<MODEV, PEV, T>(b128, b64, red_row, dst, cv, rv);                                          \
   } while (0)
-    if (fast) { if (pe) RS_STEP(true, 1); else RS_STEP(true, 0); }
-    else { if (pe) RS_STEP(false, 1); else RS_STEP(false, 0); }
+    if (fast && inner) { if (pe) RS_STEP(INNER, 1); else RS_STEP(INNER, 0); }
+    else if (fast) { if (pe) RS_STEP(FASTM, 1); else RS_STEP(FASTM, 0); }
+    else { if (pe) RS_STEP(SLOW, 1); else RS_STEP(SLOW, 0); }
 #undef RS_STEP
+#undef RS_PHASE_BARRIER
   }
 }
 

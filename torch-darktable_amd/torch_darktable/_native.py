@@ -10,7 +10,16 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 _LIB_PATH = Path(__file__).resolve().parent / 'libtdk_hip.so'
+# Measurement knob (profiles/ab_*.sh, profiles/rcd_ab.py): load another build of the same library (an experiment variant under
+# variants/) instead of copying it over the in-tree one.  Never set by the product, the tests or bench.py; announced on stderr.
+if os.environ.get('TDK_LIB_PATH'):
+  _LIB_PATH = Path(os.environ['TDK_LIB_PATH']).resolve()
+  import sys as _sys
+
+  print(f'torch_darktable: loading the kernel library from TDK_LIB_PATH={_LIB_PATH}', file=_sys.stderr)
 
 c_void_p, c_int, c_int64, c_uint32, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
 
