@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TDK_ABI_VERSION 1
+#define TDK_ABI_VERSION 2
 
 typedef void* tdk_stream_t; /* hipStream_t */
 
@@ -78,10 +78,12 @@ int tdk_ppg(const void* bayer, void* rgb, void* workspace, int width, int height
  * with the reference's first-call (zero-initialised scratch) semantics.  width must be even. */
 size_t tdk_rcd_workspace_bytes(int width, int height);
 int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream);
-/* Test hook, process-wide: 0 = automatic (frames at least 128 x 64 whose rows load as sample pairs: column strips walked
- * down the frame, csrc/tdk_rcd_stream.h; otherwise 64 x 64 LDS tiles), 1 = always the tile kernel.  Both give the same
- * bits; tests compare them. */
-int tdk_rcd_select_path(int path);
+/* The same with per-call flags.  Frames of at least 128 x 64 whose rows load and store as sample pairs run as column strips
+ * walked down the frame (csrc/tdk_rcd_stream.h), the others as 64 x 64 LDS tiles; TDK_RCD_TILE_KERNEL takes the tile kernel
+ * for any frame.  Both give the same bits (the GPU tests compare them through this flag); nothing is process-global. */
+#define TDK_RCD_TILE_KERNEL 1u
+int tdk_rcd_ex(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, unsigned flags,
+               tdk_stream_t stream);
 
 /* decode12_float -> apply_white_balance -> RCD.process as ONE call -- the head of the reference pipeline
  * (torch_darktable/pipeline/image_processor.py:190-255: load_bytes, debayer) -- bit for bit the result of the three
@@ -193,20 +195,34 @@ int tdk_wiener_log_luminance(const void* rgb_in, void* rgb_out, void* workspace,
 int tdk_wiener_log_luminance_lum(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, int tile_size, int overlap_factor,
                                  const float* sigma, float eps, int dtype, float* lum_out, int lum_log_mode, float lum_eps, tdk_stream_t stream);
 
-/* ---- Bilateral.process: reference csrc/local_contrast/bilateral.cu:358-385 (extension.cpp:111-121) */
+/* ---- Bilateral.process: reference csrc/local_contrast/bilateral.cu:358-385 (extension.cpp:111-121).
+ * sigma_s <= 4 (the pipeline default 2): one LDS tile kernel; otherwise splat / blur / blur / slice as in bilateral.cu. */
 int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]);
 size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
 int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
                   float detail, int dtype, tdk_stream_t stream);
-/* Test hook, process-wide: 0 = automatic (sigma_s <= 4: one LDS tile kernel; otherwise splat / blur / blur / slice as in
- * bilateral.cu:358-385), 1 = always the four-kernel path.  Both give the same bits; tests compare them. */
-int tdk_bilateral_select_path(int path);
 
 /* Bilateral.process_rgb / process_log_rgb as ONE call (reference torch_darktable/local_contrast.py:109-125:
  * compute_[log_]luminance -> Bilateral.process -> modify_[log_]luminance). */
 size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r);
 int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
                       int log_mode, float eps, int dtype, tdk_stream_t stream);
+
+/* The workspace of a Bilateral object outlives its calls (the reference keeps its grids in BilateralImpl and drops them when a
+ * sigma changes, bilateral.cu:389-390).  What the tile kernel keeps there are its axis tables: cell ranges, sample coordinates
+ * and splat weights per tile column / row, a function of (width, height, sigma_s, sigma_r) only.  tdk_bilateral_prepare builds
+ * them once, at the start of a workspace of either layout (plane or rgb: same place); a later call on the same workspace,
+ * geometry and sigmas passes TDK_BILATERAL_PREPARED and skips the table launch.  Without the flag every call builds them
+ * itself (the plain entry points above).  TDK_BILATERAL_GENERAL_PATH takes the four-kernel path where the tile kernel would
+ * run (same bits; the GPU tests compare the two through it).  lum_in of the rgb form: the fp32 plane
+ * compute_[log_]luminance(rgb_in) if the caller has it (16-byte aligned), or NULL. */
+#define TDK_BILATERAL_PREPARED 1u
+#define TDK_BILATERAL_GENERAL_PATH 2u
+int tdk_bilateral_prepare(void* workspace, int width, int height, float sigma_s, float sigma_r, tdk_stream_t stream);
+int tdk_bilateral_ex(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
+                     int dtype, unsigned flags, tdk_stream_t stream);
+int tdk_bilateral_rgb_ex(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
+                         float sigma_r, float detail, int log_mode, float eps, int dtype, unsigned flags, tdk_stream_t stream);
 
 /* Bilateral.process_rgb / process_log_rgb when the producer of rgb_in already has the fp32 (H, W) plane
  * compute_[log_]luminance(rgb_in) (tdk_wiener_log_luminance_lum): the extraction pass is skipped, the result is the same. */

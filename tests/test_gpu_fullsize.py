@@ -69,7 +69,7 @@ def test_rcd_strips_equal_tiles_on_whole_frames(td, dev, shape):
     """The column strips (csrc/tdk_rcd_stream.h) and the 64 x 64 tile kernel must agree on EVERY pixel of a full-size frame --
     all strip and segment seams, the moved-back last strip / segment, the border rules on all four sides and the ring -- for
     fp32 and fp16 storage and a second CFA phase.  (The windows above tie the result to the oracle.)"""
-    from torch_darktable._native import lib
+    from torch_darktable import torch_darktable_extension as ext
     from torch_darktable.synthetic import synthetic_bayer
 
     w, h = shape
@@ -78,11 +78,8 @@ def test_rcd_strips_equal_tiles_on_whole_frames(td, dev, shape):
         ws = td.RCD(dev, (w, h), pattern)
         for x in (bayer, bayer.half()):
             strips = ws.process(x)
-            assert lib.tdk_rcd_select_path(1) == 0
-            try:
+            with ext.verification_paths(rcd_tiles=True):
                 tiles = ws.process(x)
-            finally:
-                assert lib.tdk_rcd_select_path(0) == 0
             assert torch.equal(strips, tiles), f'{shape} {pattern} {x.dtype}: {(strips != tiles).sum().item()} values differ'
             del strips, tiles
 

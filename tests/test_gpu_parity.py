@@ -130,12 +130,9 @@ def test_rcd_strips_equal_tiles(td, oracle, dev, scene, pattern, size):
     ref16 = oracle.rcd(b16.astype(np.float32), oracle.PATTERNS[pattern]).astype(np.float16)
     ws = td.RCD(dev, (w, h), td.BayerPattern[pattern])
     strips, strips16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
-    from torch_darktable._native import lib
-    assert lib.tdk_rcd_select_path(1) == 0
-    try:
+    from torch_darktable import torch_darktable_extension as ext
+    with ext.verification_paths(rcd_tiles=True):
         tiles, tiles16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
-    finally:
-        assert lib.tdk_rcd_select_path(0) == 0
     for name, got, want in (('strips', strips, ref), ('tiles', tiles, ref), ('strips f16', strips16, ref16), ('tiles f16', tiles16, ref16)):
         bad = np.argwhere(got != want)
         assert bad.size == 0, f'{name}: {len(bad)} mismatches, first at {bad[:5].tolist()}'
@@ -145,7 +142,7 @@ def test_rcd_strips_equal_tiles_on_many_geometries(td, dev):
     """Strip / segment geometry sweep: widths around the multiples of the 108-column strip (one strip exactly, a last strip
     moved back by 2 .. 106 columns), heights around the segment rules (64 = the minimum, odd, one row more than a multiple of
     the 8-row step), all against the tile kernel (itself tied to the oracle above) on every pixel."""
-    from torch_darktable._native import lib
+    from torch_darktable import torch_darktable_extension as ext
     rng = np.random.default_rng(2024)
     widths = [128, 130, 214, 216, 218, 234, 322, 324, 326, 1000]
     heights = [64, 65, 71, 72, 73, 127, 128, 129, 200, 333]
@@ -155,11 +152,8 @@ def test_rcd_strips_equal_tiles_on_many_geometries(td, dev):
         pattern = [td.BayerPattern.RGGB, td.BayerPattern.BGGR, td.BayerPattern.GRBG, td.BayerPattern.GBRG][(w // 2 + h) % 4]
         ws = td.RCD(dev, (w, h), pattern)
         strips = ws.process(bayer)
-        assert lib.tdk_rcd_select_path(1) == 0
-        try:
+        with ext.verification_paths(rcd_tiles=True):
             tiles = ws.process(bayer)
-        finally:
-            assert lib.tdk_rcd_select_path(0) == 0
         assert torch.equal(strips, tiles), f'{w}x{h} {pattern}: {(strips != tiles).sum().item()} values differ'
 
 
@@ -439,21 +433,18 @@ def test_bilateral_tile_kernel(td, oracle, dev, scene, sig, size):
     assert np.array_equal(got16, oracle.bilateral(lum16.astype(np.float32), sig[0], sig[1], 0.4).astype(np.float16))
     rgb_fused = npy(ws.process_rgb(gpu(img, dev), 0.4))
     log_fused = npy(ws.process_log_rgb(gpu(img, dev), 0.4))
-    from torch_darktable._native import lib
-    assert lib.tdk_bilateral_select_path(1) == 0  # the general four-kernel path, same parameters
-    try:
+    from torch_darktable import torch_darktable_extension as ext
+    with ext.verification_paths(bilateral_general=True):  # the general four-kernel path, same parameters
         assert np.array_equal(npy(ws.process(gpu(lum, dev), 0.4)), got)
         assert np.array_equal(npy(ws.process_rgb(gpu(img, dev), 0.4)), rgb_fused)
         assert np.array_equal(npy(ws.process_log_rgb(gpu(img, dev), 0.4)), log_fused)
-    finally:
-        assert lib.tdk_bilateral_select_path(0) == 0
 
 
 def test_bilateral_tile_kernel_geometry_sweep(td, dev):
     """The tile kernel's per-launch axis tables and fixed sample window over many frame sizes and sigmas (tile counts that end
     in partial tiles on either axis, widths that are / are not multiples of 4, sigma_s from 1 to 4 with non-integer values,
     short and long z columns): the tile path must equal the four-kernel path bit for bit, for planes and the RGB epilogue."""
-    from torch_darktable._native import lib
+    from torch_darktable import torch_darktable_extension as ext
     rng = np.random.default_rng(99)
     cases = [(64, 32, 2.0, 0.2), (65, 33, 2.0, 0.2), (128, 64, 1.5, 0.25), (130, 70, 4.0, 0.1), (67, 200, 3.3, 0.05), (400, 37, 1.0, 0.25), (36, 40, 2.7, 0.02)]
     cases += [(int(rng.integers(40, 500)), int(rng.integers(40, 300)), float(rng.uniform(1.0, 4.0)), float(rng.choice([0.02, 0.07, 0.1, 0.2, 0.25]))) for _ in range(12)]
@@ -462,11 +453,8 @@ def test_bilateral_tile_kernel_geometry_sweep(td, dev):
         rgb = torch.from_numpy(rng.random((h, w, 3), dtype=np.float32)).to(dev)
         ws = td.Bilateral(dev, (w, h), sigma_s=ss, sigma_r=sr)
         a, a16, argb = ws.process(lum, 0.4), ws.process(lum.half(), 0.4), ws.process_rgb(rgb, 0.4)
-        assert lib.tdk_bilateral_select_path(1) == 0
-        try:
+        with ext.verification_paths(bilateral_general=True):  # the general four-kernel path, same parameters
             b, b16, brgb = ws.process(lum, 0.4), ws.process(lum.half(), 0.4), ws.process_rgb(rgb, 0.4)
-        finally:
-            assert lib.tdk_bilateral_select_path(0) == 0
         for name, x, y in (('plane', a, b), ('plane f16', a16, b16), ('rgb', argb, brgb)):
             assert torch.equal(x, y), f'{w}x{h} sigma ({ss:.3f}, {sr}) {name}: {(x != y).sum().item()} values differ'
     # samples outside the range of the exact-quotient shortcut (zeros, denormals, huge, negative, inf, nan): the tile kernel's
@@ -479,11 +467,8 @@ def test_bilateral_tile_kernel_geometry_sweep(td, dev):
     lum_t = torch.from_numpy(lum).to(dev)
     ws = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
     a = ws.process(lum_t, 0.4)
-    assert lib.tdk_bilateral_select_path(1) == 0
-    try:
+    with ext.verification_paths(bilateral_general=True):  # the general four-kernel path, same parameters
         b = ws.process(lum_t, 0.4)
-    finally:
-        assert lib.tdk_bilateral_select_path(0) == 0
     same = (a == b) | (torch.isnan(a) & torch.isnan(b))
     assert bool(same.all()), f'special values: {(~same).sum().item()} values differ'
 

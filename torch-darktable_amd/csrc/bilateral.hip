@@ -24,8 +24,6 @@
 //  formulas (x + 0 == x); and the gather sums in raster order, so the whole op is bit-identical to the oracle.
 #include <stdlib.h>
 
-#include <atomic>
-
 #include "tdk_color.h"
 
 #ifdef TDK_BIL_TIMING
@@ -710,13 +708,9 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;  // two workgroups per CU
 
-// test hook (tdk_bilateral_select_path): take the general four-kernel path even where the tile kernel applies
-static std::atomic<int> g_force_general_path{0};
-
 // Decide whether the tile kernel applies and size its LDS.  Returns false -> four-kernel path.
 // sigma_s <= 4: the pixels with a positive weight on one cell lie within sigma_s of it on either side, at most 7 <= TAB_W.
 static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail, TileLds* L, size_t* lds_bytes) {
-  if (g_force_general_path.load(std::memory_order_relaxed)) return false;
   if (!(sigma_s >= 1.0f && sigma_s <= 4.0f)) return false;
   // no pixel may be clamped onto the last column / row (those columns collect far-away pixels)
   if ((float)(width - 1) / sigma_s > (float)(d.sx - 1) || (float)(height - 1) / sigma_s > (float)(d.sy - 1)) return false;
@@ -758,7 +752,8 @@ static bool plan_tiles(int width, int height, const GridDims& d, float sigma_s, 
   return *lds_bytes <= FUSED_LDS_LIMIT;
 }
 
-// bytes of the per-launch axis tables (0 when the tile kernel does not apply); they sit behind everything else in the workspace
+// bytes of the axis tables (0 when the tile kernel does not apply for this geometry); they are the FIRST thing in a
+// workspace of either layout, so one tdk_bilateral_prepare serves the plane and the RGB entry points alike
 static size_t tile_table_bytes(int width, int height, float sigma_s, float sigma_r) {
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
   TileLds L;
@@ -768,12 +763,21 @@ static size_t tile_table_bytes(int width, int height, float sigma_s, float sigma
   return tdk_align_up(words * sizeof(int), 256);
 }
 
+static int build_tables(int* tab, int width, int height, const GridDims& d, float sigma_s, const TileLds& L, hipStream_t s) {
+  const int tiles_x = tdk_div_up(width, FTW), tiles_y = tdk_div_up(height, FTH);
+  TDK_LAUNCH("tdk_bilateral(tables)", bilateral_axis_tables_kernel, dim3(tiles_x + tiles_y), dim3(64), 0, s, tab, width, height, d, sigma_s, tiles_x, L);
+  return TDK_OK;
+}
+
 template <typename TL, typename T, int MODE>
 int launch_tiles(const TL* lum, const T* rgb, T* out, int* tab, int width, int height, const GridDims& d, float sigma_s, float sigma_r, float detail,
-                 const TileLds& L, size_t lds_bytes, bool vec, hipStream_t s) {
+                 const TileLds& L, size_t lds_bytes, bool vec, bool prepared, hipStream_t s) {
   const int tiles_x = tdk_div_up(width, FTW), tiles_y = tdk_div_up(height, FTH), ntiles = tiles_x * tiles_y;
   const dim3 grid(8 * tdk_div_up(ntiles, 8));
-  TDK_LAUNCH("tdk_bilateral(tables)", bilateral_axis_tables_kernel, dim3(tiles_x + tiles_y), dim3(64), 0, s, tab, width, height, d, sigma_s, tiles_x, L);
+  if (!prepared) {  // the tables depend on the geometry and the sigmas only: a caller that keeps its workspace builds them once (tdk_bilateral_prepare)
+    const int rc = build_tables(tab, width, height, d, sigma_s, L, s);
+    if (rc != TDK_OK) return rc;
+  }
 #define TDK_BT(VECV)                                                                                                                              \
   do {                                                                                                                                            \
     TDK_MAX_LDS_ONCE((bilateral_tile_kernel<TL, T, MODE, VECV>), "tdk_bilateral(hipFuncSetAttribute)");                                           \
@@ -785,10 +789,11 @@ int launch_tiles(const TL* lum, const T* rgb, T* out, int* tab, int width, int h
   return TDK_OK;
 }
 
-// workspace layout: grid | tmp | [fp32 luminance plane (rgb entry points)] | axis tables of the tile kernel
-static size_t grid_workspace_bytes(const GridDims& d) { return tdk_align_up(2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) * sizeof(float), 256); }
-static size_t rgb_workspace_bytes(const GridDims& d, int width, int height) {
-  return tdk_align_up((2 * tdk_align_up((size_t)d.sx * d.sy * d.sz, 64) + (size_t)width * height) * sizeof(float), 256);
+// workspace layout: axis tables of the tile kernel | grid | tmp | [fp32 luminance plane (rgb entry points)]
+static size_t grid_floats(const GridDims& d) { return tdk_align_up((size_t)d.sx * d.sy * d.sz, 64); }
+static size_t plane_workspace_bytes(const GridDims& d, size_t tables) { return tables + tdk_align_up(2 * grid_floats(d) * sizeof(float), 256); }
+static size_t rgb_workspace_bytes(const GridDims& d, int width, int height, size_t tables) {
+  return tables + tdk_align_up((2 * grid_floats(d) + (size_t)width * height) * sizeof(float), 256);
 }
 
 // splat -> blur x,y -> z derivative; leaves the final grid in `grid`
@@ -814,18 +819,21 @@ inline unsigned stream_blocks(int64_t npix) {
 }
 
 template <typename T>
-int launch(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, hipStream_t s) {
+int launch(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, unsigned flags, hipStream_t s) {
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  const size_t ncell = (size_t)d.sx * d.sy * d.sz;
-  float* grid = reinterpret_cast<float*>(workspace);
-  float* tmp = grid + tdk_align_up(ncell, 64);
+  const size_t tables = tile_table_bytes(width, height, sigma_s, sigma_r);
+  int* tab = reinterpret_cast<int*>(workspace);
+  float* grid = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tables);
+  float* tmp = grid + grid_floats(d);
   const T* in = reinterpret_cast<const T*>(lum_in);
   TileLds L;
   size_t lds_bytes = 0;
-  if (lum_in != lum_out && plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {  // tiles read a pixel halo: not in place
+  const bool tiles = !(flags & TDK_BILATERAL_GENERAL_PATH) && lum_in != lum_out  // tiles read a pixel halo: not in place
+                     && plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes);
+  if (tiles) {
     const bool vec = (width % 4) == 0 && tdk_aligned(lum_in, 16) && tdk_aligned(lum_out, 16);
-    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + grid_workspace_bytes(d));
-    return launch_tiles<T, T, 0>(in, nullptr, reinterpret_cast<T*>(lum_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+    return launch_tiles<T, T, 0>(in, nullptr, reinterpret_cast<T*>(lum_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec,
+                                 (flags & TDK_BILATERAL_PREPARED) != 0, s);
   }
   const int rc = build_grid<T>(in, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
@@ -836,15 +844,16 @@ int launch(const void* lum_in, void* lum_out, void* workspace, int width, int he
 
 template <typename T>
 int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, int log_mode, float eps,
-               int dtype, hipStream_t s, const float* lum_in = nullptr) {
+               int dtype, unsigned flags, hipStream_t s, const float* lum_in = nullptr) {
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  const size_t ncell = (size_t)d.sx * d.sy * d.sz;
-  float* grid = reinterpret_cast<float*>(workspace);
-  float* tmp = grid + tdk_align_up(ncell, 64);
+  const size_t tables = tile_table_bytes(width, height, sigma_s, sigma_r);
+  int* tab = reinterpret_cast<int*>(workspace);
+  float* grid = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tables);
+  float* tmp = grid + grid_floats(d);
   const float* plane = lum_in;
   int rc = TDK_OK;
   if (!plane) {  // the producer of rgb_in did not hand its luminance plane over: extract it
-    float* mine = tmp + tdk_align_up(ncell, 64);
+    float* mine = tmp + grid_floats(d);
     rc = tdk_compute_luminance(rgb_in, mine, (int64_t)width * height, log_mode, eps, dtype, TDK_F32, reinterpret_cast<tdk_stream_t>(s));
     if (rc != TDK_OK) return rc;
     plane = mine;
@@ -852,10 +861,10 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
   const bool vec = (width % 4) == 0 && tdk_aligned(rgb_in, 16) && tdk_aligned(rgb_out, 16) && tdk_aligned(plane, 16);
   TileLds L;
   size_t lds_bytes = 0;
-  if (plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {
-    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + rgb_workspace_bytes(d, width, height));
-    if (log_mode) return launch_tiles<float, T, 2>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
-    return launch_tiles<float, T, 1>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, s);
+  if (!(flags & TDK_BILATERAL_GENERAL_PATH) && plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {
+    const bool prepared = (flags & TDK_BILATERAL_PREPARED) != 0;
+    if (log_mode) return launch_tiles<float, T, 2>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, prepared, s);
+    return launch_tiles<float, T, 1>(plane, reinterpret_cast<const T*>(rgb_in), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes, vec, prepared, s);
   }
   rc = build_grid<float>(plane, grid, tmp, width, height, d, sigma_s, sigma_r, s);
   if (rc != TDK_OK) return rc;
@@ -873,12 +882,6 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
 
 }  // namespace
 
-TDK_EXPORT int tdk_bilateral_select_path(int path) {
-  TDK_REQUIRE(path == 0 || path == 1, "tdk_bilateral_select_path: path must be 0 (automatic) or 1 (general four-kernel path)");
-  g_force_general_path.store(path, std::memory_order_relaxed);
-  return TDK_OK;
-}
-
 TDK_EXPORT int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]) {
   TDK_REQUIRE(width > 0 && height > 0 && sigma_r > 0.0f && size_xyz, "tdk_bilateral_grid_size: invalid arguments");
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
@@ -889,41 +892,60 @@ TDK_EXPORT int tdk_bilateral_grid_size(int width, int height, float sigma_s, flo
 TDK_EXPORT size_t tdk_bilateral_workspace_bytes(int width, int height, float sigma_s, float sigma_r) {
   if (width <= 0 || height <= 0 || !(sigma_r > 0.0f)) return 0;
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  return grid_workspace_bytes(d) + tile_table_bytes(width, height, sigma_s, sigma_r);
-}
-
-TDK_EXPORT int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
-                             float detail, int dtype, tdk_stream_t stream) {
-  TDK_REQUIRE(lum_in && lum_out && workspace, "tdk_bilateral: null pointer");
-  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
-  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral: sigmas must be positive");
-  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(lum_in, lum_out, workspace, width, height, sigma_s, sigma_r, detail, tdk_stream(stream)));
-  return TDK_OK;
+  return plane_workspace_bytes(d, tile_table_bytes(width, height, sigma_s, sigma_r));
 }
 
 TDK_EXPORT size_t tdk_bilateral_rgb_workspace_bytes(int width, int height, float sigma_s, float sigma_r) {
   if (width <= 0 || height <= 0 || !(sigma_r > 0.0f)) return 0;
   const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
-  return rgb_workspace_bytes(d, width, height) + tile_table_bytes(width, height, sigma_s, sigma_r);
+  return rgb_workspace_bytes(d, width, height, tile_table_bytes(width, height, sigma_s, sigma_r));
 }
 
-TDK_EXPORT int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
-                                 int log_mode, float eps, int dtype, tdk_stream_t stream) {
+TDK_EXPORT int tdk_bilateral_prepare(void* workspace, int width, int height, float sigma_s, float sigma_r, tdk_stream_t stream) {
+  TDK_REQUIRE(workspace, "tdk_bilateral_prepare: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
+  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_prepare: sigmas must be positive");
+  const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
+  TileLds L;
+  size_t lds_bytes = 0;
+  if (!plan_tiles(width, height, d, sigma_s, sigma_r, 0.0f, &L, &lds_bytes)) return TDK_OK;  // this geometry runs the four-kernel path: nothing to prepare
+  return build_tables(reinterpret_cast<int*>(workspace), width, height, d, sigma_s, L, tdk_stream(stream));
+}
+
+TDK_EXPORT int tdk_bilateral_ex(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
+                                float detail, int dtype, unsigned flags, tdk_stream_t stream) {
+  TDK_REQUIRE(lum_in && lum_out && workspace, "tdk_bilateral: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
+  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral: sigmas must be positive");
+  TDK_REQUIRE((flags & ~(TDK_BILATERAL_PREPARED | TDK_BILATERAL_GENERAL_PATH)) == 0, "tdk_bilateral: unknown flags 0x%x", flags);
+  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(lum_in, lum_out, workspace, width, height, sigma_s, sigma_r, detail, flags, tdk_stream(stream)));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_bilateral(const void* lum_in, void* lum_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
+                             float detail, int dtype, tdk_stream_t stream) {
+  return tdk_bilateral_ex(lum_in, lum_out, workspace, width, height, sigma_s, sigma_r, detail, dtype, 0u, stream);
+}
+
+TDK_EXPORT int tdk_bilateral_rgb_ex(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
+                                    float sigma_r, float detail, int log_mode, float eps, int dtype, unsigned flags, tdk_stream_t stream) {
   TDK_REQUIRE(rgb_in && rgb_out && workspace, "tdk_bilateral_rgb: null pointer");
   TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
   TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_rgb: sigmas must be positive");
   TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
-  TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, tdk_stream(stream)));
+  TDK_REQUIRE(!lum_in || tdk_aligned(lum_in, 16), "tdk_bilateral_rgb: luminance plane must be 16-byte aligned");
+  TDK_REQUIRE((flags & ~(TDK_BILATERAL_PREPARED | TDK_BILATERAL_GENERAL_PATH)) == 0, "tdk_bilateral_rgb: unknown flags 0x%x", flags);
+  TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, flags, tdk_stream(stream), lum_in));
   return TDK_OK;
+}
+
+TDK_EXPORT int tdk_bilateral_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail,
+                                 int log_mode, float eps, int dtype, tdk_stream_t stream) {
+  return tdk_bilateral_rgb_ex(rgb_in, nullptr, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, 0u, stream);
 }
 
 TDK_EXPORT int tdk_bilateral_rgb_lum(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
                                      float sigma_r, float detail, int log_mode, float eps, int dtype, tdk_stream_t stream) {
-  TDK_REQUIRE(rgb_in && lum_in && rgb_out && workspace, "tdk_bilateral_rgb_lum: null pointer");
-  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
-  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_rgb_lum: sigmas must be positive");
-  TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
-  TDK_REQUIRE(tdk_aligned(lum_in, 16), "tdk_bilateral_rgb_lum: luminance plane must be 16-byte aligned");
-  TDK_DISPATCH_DTYPE(dtype, T, return launch_rgb<T>(rgb_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, tdk_stream(stream), lum_in));
-  return TDK_OK;
+  TDK_REQUIRE(lum_in, "tdk_bilateral_rgb_lum: null pointer");
+  return tdk_bilateral_rgb_ex(rgb_in, lum_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, log_mode, eps, dtype, 0u, stream);
 }

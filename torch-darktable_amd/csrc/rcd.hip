@@ -26,8 +26,6 @@
 // border ring (3x3 average + PPG-style green / red-blue, rcd.cu:285-493 and ppg.cu:342-389) is
 // computed by the first ~100 workgroups of the same launch.  Arithmetic: same operation order as
 // the oracle, no FMA contraction, IEEE divides -> bit-exact.
-#include <atomic>
-
 #include "tdk_fastdiv.h"
 #include "tdk_stencils.h"
 
@@ -697,11 +695,8 @@ __global__ __launch_bounds__(NT) void rcd_interior(const TI* __restrict__ in, T*
   }
 }
 
-// test hook (tdk_rcd_select_path): take the tile kernel even where the strips apply
-static std::atomic<int> g_force_tile_path{0};
-
 template <typename TI, typename T>
-int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) {
+int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, unsigned flags, hipStream_t s) {
   const TI* in = reinterpret_cast<const TI*>(bayer);
   T* out = reinterpret_cast<T*>(rgb);
   const int wide_ok = tdk_aligned(bayer, 2 * sizeof(TI));  // sample pairs load as one 8-B / 4-B access (w is even)
@@ -715,7 +710,8 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   if (w > 14 && h > 14) {
     const int nborder = (int)tdk_div_up64(nring, NT), tiles_x = tdk_div_up(w, TW), tiles_y = tdk_div_up(h, TH);
     // Frames that hold a strip (and whose samples load as pairs) go to rcd_stream, ring included.
-    bool stream = wide_ok && w >= rs::TWS + 2 * rs::HALO && h >= 64 && !g_force_tile_path.load(std::memory_order_relaxed);
+    // (the strips also store pixel pairs: 8-B / 4-B aligned output; an offset view takes the tile kernel)
+    bool stream = wide_ok && tdk_aligned(rgb, 2 * sizeof(T)) && w >= rs::TWS + 2 * rs::HALO && h >= 64 && !(flags & TDK_RCD_TILE_KERNEL);
 #ifdef TDK_EXPERIMENTS
     if (const char* e = getenv("TDK_RCD_STREAM")) stream = stream && atoi(e) != 0;
 #endif
@@ -727,7 +723,9 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
       if (nsegs < 1) nsegs = 1;
       if (nsegs > h / 64) nsegs = h / 64;
       int seg_rows = (tdk_div_up(h, nsegs) + 1) & ~1;  // even: segment origins keep the CFA phase
-      if (seg_rows > h) seg_rows = h & ~1;
+      // a single segment of an odd-height frame: its origin is row 0 whatever its length, so it may be odd (two
+      // overlapping segments of h - 1 rows would each walk nearly the whole frame)
+      if (seg_rows > h) seg_rows = nsegs == 1 ? h : (h & ~1);
       nsegs = tdk_div_up(h, seg_rows);
       const int nwg = nstrips * nsegs;
       const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
@@ -753,26 +751,28 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, h
   return TDK_OK;
 }
 
-template <typename T> int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, hipStream_t s) { return launch_mixed<T, T>(bayer, rgb, w, h, pattern, s); }
+template <typename T> int launch(const void* bayer, void* rgb, int w, int h, uint32_t pattern, unsigned flags, hipStream_t s) {
+  return launch_mixed<T, T>(bayer, rgb, w, h, pattern, flags, s);
+}
 
 }  // namespace
 
 TDK_EXPORT size_t tdk_rcd_workspace_bytes(int, int) { return 0; }
 
-TDK_EXPORT int tdk_rcd_select_path(int path) {
-  TDK_REQUIRE(path == 0 || path == 1, "tdk_rcd_select_path: path must be 0 (automatic) or 1 (tile kernel)");
-  g_force_tile_path.store(path, std::memory_order_relaxed);
-  return TDK_OK;
-}
-
-TDK_EXPORT int tdk_rcd(const void* bayer, void* rgb, void* /*workspace*/, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream) {
+TDK_EXPORT int tdk_rcd_ex(const void* bayer, void* rgb, void* /*workspace*/, int width, int height, uint32_t pattern, int dtype, unsigned flags,
+                          tdk_stream_t stream) {
   TDK_REQUIRE(bayer && rgb, "tdk_rcd: null pointer");
   TDK_REQUIRE(width > 0 && height > 0, "tdk_rcd: invalid size %dx%d", width, height);
   TDK_REQUIRE((width & 1) == 0, "tdk_rcd: width must be even (the reference packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
               "tdk_rcd: invalid Bayer pattern 0x%08x", pattern);
-  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, tdk_stream(stream)));
+  TDK_REQUIRE((flags & ~TDK_RCD_TILE_KERNEL) == 0, "tdk_rcd: unknown flags 0x%x", flags);
+  TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, flags, tdk_stream(stream)));
   return TDK_OK;
+}
+
+TDK_EXPORT int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, tdk_stream_t stream) {
+  return tdk_rcd_ex(bayer, rgb, workspace, width, height, pattern, dtype, 0u, stream);
 }
 
 // decode12_float -> apply_white_balance -> RCD.process as one call.  Two launches: a streaming kernel that decodes and
@@ -796,8 +796,8 @@ TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* works
   float* mosaic = reinterpret_cast<float*>(workspace);
   const int rc = tdk_decode12_wb_plane(packed, mosaic, gains, width, height, pattern, ids_format, tdk_stream(stream));
   if (rc != TDK_OK) return rc;
-  if (out_dtype == TDK_F32) return launch_mixed<float, float>(mosaic, rgb, width, height, pattern, tdk_stream(stream));
-  if (out_dtype == TDK_F16) return launch_mixed<float, __half>(mosaic, rgb, width, height, pattern, tdk_stream(stream));
+  if (out_dtype == TDK_F32) return launch_mixed<float, float>(mosaic, rgb, width, height, pattern, 0u, tdk_stream(stream));
+  if (out_dtype == TDK_F16) return launch_mixed<float, __half>(mosaic, rgb, width, height, pattern, 0u, tdk_stream(stream));
   tdk_set_error("unsupported dtype tag %d", out_dtype);
   return TDK_ERR_INVALID_ARGUMENT;
 }

@@ -87,8 +87,8 @@ __device__ __forceinline__ v2f win_fma(int y, v2f x, v2f c) {
 // Partner exchange of the gains step, in place: x <- x of lane ^ 1 in every lane except the two self-conjugate lanes of each
 // 32-lane slot, which keep their own value.  EXEC is narrowed to the exchanging lanes around the DPP moves (a lane that is
 // switched off keeps its register, and the moves that would read it are switched off too), which saves the select that
-// partner2() needs per value; one EXEC round trip serves a batch of up to 14 registers.  Only valid where EXEC is all ones
-// (the column stage sits under wave-uniform branches).
+// partner2() needs per value; one EXEC round trip serves a batch of up to 14 registers.  (The exchange assumes that both
+// lanes of a pair are active, as they are under the wave-uniform branches of the column stage.)
 #define YS_DPP1(r) "v_mov_b32_dpp %[" #r "], %[" #r "] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 template <int N> __device__ __forceinline__ void partner_swap(v2f* (&r)[N]) {
   static_assert(N >= 1 && N <= 7, "at most 14 registers per batch (asm operand limit)");
@@ -98,19 +98,26 @@ template <int N> __device__ __forceinline__ void partner_swap(v2f* (&r)[N]) {
   for (int i = 0; i < N; i++) { v[2 * i] = r[i]->x; v[2 * i + 1] = r[i]->y; }
 #pragma unroll
   for (int i = 2 * N; i < 14; i++) v[i] = 0.0f;
-  // s_nop 1: a VALU write needs two wait states before a DPP read of the same register
+  // s_nop 1: a VALU write needs two wait states before a DPP read of the same register.  EXEC is saved and restored (not forced
+  // back to all ones), so the exchange stays correct if a caller ever sits under a narrowed EXEC.
+  unsigned long long sv;
   if constexpr (N == 7)
-    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) YS_DPP1(e) YS_DPP1(f) YS_DPP1(g) YS_DPP1(h) YS_DPP1(i) YS_DPP1(j)
-                 YS_DPP1(k) YS_DPP1(l) YS_DPP1(n) YS_DPP1(o) "s_mov_b64 exec, -1"
+    asm volatile("s_nop 1\n\ts_and_saveexec_b64 %[sv], %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) YS_DPP1(e) YS_DPP1(f) YS_DPP1(g) YS_DPP1(h) YS_DPP1(i) YS_DPP1(j)
+                 YS_DPP1(k) YS_DPP1(l) YS_DPP1(n) YS_DPP1(o) "s_mov_b64 exec, %[sv]"
                  : [a] "+v"(v[0]), [b] "+v"(v[1]), [c] "+v"(v[2]), [d] "+v"(v[3]), [e] "+v"(v[4]), [f] "+v"(v[5]), [g] "+v"(v[6]), [h] "+v"(v[7]), [i] "+v"(v[8]),
-                   [j] "+v"(v[9]), [k] "+v"(v[10]), [l] "+v"(v[11]), [n] "+v"(v[12]), [o] "+v"(v[13])
-                 : [m] "s"(EXCH));
+                   [j] "+v"(v[9]), [k] "+v"(v[10]), [l] "+v"(v[11]), [n] "+v"(v[12]), [o] "+v"(v[13]), [sv] "=&s"(sv)
+                 : [m] "s"(EXCH)
+                 : "scc");
   else if constexpr (N == 2)
-    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) "s_mov_b64 exec, -1"
-                 : [a] "+v"(v[0]), [b] "+v"(v[1]), [c] "+v"(v[2]), [d] "+v"(v[3])
-                 : [m] "s"(EXCH));
+    asm volatile("s_nop 1\n\ts_and_saveexec_b64 %[sv], %[m]\n\t" YS_DPP1(a) YS_DPP1(b) YS_DPP1(c) YS_DPP1(d) "s_mov_b64 exec, %[sv]"
+                 : [a] "+v"(v[0]), [b] "+v"(v[1]), [c] "+v"(v[2]), [d] "+v"(v[3]), [sv] "=&s"(sv)
+                 : [m] "s"(EXCH)
+                 : "scc");
   else
-    asm volatile("s_nop 1\n\ts_mov_b64 exec, %[m]\n\t" YS_DPP1(a) YS_DPP1(b) "s_mov_b64 exec, -1" : [a] "+v"(v[0]), [b] "+v"(v[1]) : [m] "s"(EXCH));
+    asm volatile("s_nop 1\n\ts_and_saveexec_b64 %[sv], %[m]\n\t" YS_DPP1(a) YS_DPP1(b) "s_mov_b64 exec, %[sv]"
+                 : [a] "+v"(v[0]), [b] "+v"(v[1]), [sv] "=&s"(sv)
+                 : [m] "s"(EXCH)
+                 : "scc");
 #pragma unroll
   for (int i = 0; i < N; i++) *r[i] = v2f{v[2 * i], v[2 * i + 1]};
 }

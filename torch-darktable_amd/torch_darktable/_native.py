@@ -40,7 +40,7 @@ SIGNATURES = {
   'tdk_ppg': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_float, c_int, c_void_p]),
   'tdk_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_void_p]),
-  'tdk_rcd_select_path': (c_int, [c_int]),
+  'tdk_rcd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, C.c_uint, c_void_p]),
   'tdk_decode12_wb_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_decode12_wb_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p]),
   'tdk_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -68,7 +68,9 @@ SIGNATURES = {
   'tdk_bilateral_rgb_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
   'tdk_bilateral_grid_size': (c_int, [c_int, c_int, c_float, c_float, C.POINTER(c_int)]),
   'tdk_bilateral_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),
-  'tdk_bilateral_select_path': (c_int, [c_int]),
+  'tdk_bilateral_prepare': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+  'tdk_bilateral_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, C.c_uint, c_void_p]),
+  'tdk_bilateral_rgb_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, C.c_uint, c_void_p]),
   'tdk_bilateral': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
   'tdk_bilateral_rgb_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),
   'tdk_bilateral_rgb': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
@@ -90,8 +92,8 @@ def load() -> C.CDLL:
     fn = getattr(lib, name)  # AttributeError here == ABI mismatch between header and library
     fn.restype = restype
     fn.argtypes = argtypes
-  if lib.tdk_abi_version() != 1:
-    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 1')
+  if lib.tdk_abi_version() != 2:
+    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 2')
   return lib
 
 

@@ -40,7 +40,15 @@ class Wiener:
 
     def _sigmas(self, noise, channels: int) -> torch.Tensor:
         if isinstance(noise, float):
-            return torch.full((channels,), noise, dtype=torch.float32, device=self._device)
+            # one small device tensor per (value, channels), kept: a fill launch per call is a latency-bound launch per frame
+            cache = self.__dict__.setdefault('_sigma_cache', {})
+            key = (noise, channels)
+            t = cache.get(key)
+            if t is None:
+                if len(cache) >= 16:
+                    cache.clear()
+                t = cache[key] = torch.full((channels,), noise, dtype=torch.float32, device=self._device)
+            return t
         if isinstance(noise, torch.Tensor):
             if noise.shape != (channels,):
                 raise ValueError(f'noise tensor must have {channels} elements for {channels}-channel image')

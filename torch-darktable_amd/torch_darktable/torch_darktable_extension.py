@@ -19,8 +19,10 @@ all deliberate:
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import enum
+import threading
 from typing import Sequence
 
 import torch
@@ -46,6 +48,26 @@ class BayerPattern(enum.IntEnum):
   BGGR = 0x16161616
   GRBG = 0x61616161
   GBRG = 0x49494949
+
+
+# ------------------------------------------------------------------ verification paths
+# Two ops have a second kernel path that gives the same bits (RCD: 64 x 64 LDS tiles instead of the column strips; Bilateral:
+# the four-kernel path instead of the LDS tile kernel).  The library selects per call (the `flags` of tdk_rcd_ex /
+# tdk_bilateral_ex); this thread-local context is how the GPU tests ask for the other path.  Nothing is process-global.
+TDK_RCD_TILE_KERNEL, TDK_BILATERAL_PREPARED, TDK_BILATERAL_GENERAL_PATH = 1, 1, 2
+_verify = threading.local()
+
+
+@contextlib.contextmanager
+def verification_paths(rcd_tiles: bool = False, bilateral_general: bool = False):
+  """Inside the context (this thread only) RCD.process takes the tile kernel and / or Bilateral the four-kernel path."""
+  old = (getattr(_verify, 'rcd', 0), getattr(_verify, 'bil', 0))
+  _verify.rcd = TDK_RCD_TILE_KERNEL if rcd_tiles else 0
+  _verify.bil = TDK_BILATERAL_GENERAL_PATH if bilateral_general else 0
+  try:
+    yield
+  finally:
+    _verify.rcd, _verify.bil = old
 
 
 # ------------------------------------------------------------------ helpers
@@ -227,7 +249,7 @@ class RCD(_Workspace):
     self._check_size(x)
     out = torch.empty((self._height, self._width, 3), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-      check(lib.tdk_rcd(_ptr(x), _ptr(out), None, self._width, self._height, self._pattern, _dtype_tag(x), _stream()))
+      check(lib.tdk_rcd_ex(_ptr(x), _ptr(out), None, self._width, self._height, self._pattern, _dtype_tag(x), getattr(_verify, 'rcd', 0), _stream()))
     return out
 
 
@@ -667,6 +689,23 @@ class Bilateral(_Workspace):
     check(lib.tdk_bilateral_grid_size(self._width, self._height, self._sigma_s, self._sigma_r, sz))
     return tuple(sz)
 
+  def _prepared_workspace(self, nbytes: int, device: torch.device) -> tuple[torch.Tensor, int]:
+    """The per-stream workspace and the flags of a call on it.  The tile kernel's axis tables live at the start of the
+    workspace and depend on the geometry and the sigmas only: they are built when a workspace buffer is (re)allocated
+    (tdk_bilateral_prepare) and every later call vouches for them -- the reference likewise keeps its grids in the object and
+    drops them when a sigma changes (bilateral.cu:389-390; the sigma setters above drop the workspaces)."""
+    ws = self._workspace(nbytes, device)
+    ready = self.__dict__.setdefault('_tables_ready', {})
+    key = torch.cuda.current_stream(device).cuda_stream
+    if ready.get(key) is not ws:  # the buffer object itself, not its address: a freed block can come back at the same address
+      check(lib.tdk_bilateral_prepare(_ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, _stream()))
+      ready[key] = ws
+    return ws, TDK_BILATERAL_PREPARED | getattr(_verify, 'bil', 0)
+
+  def _drop_workspaces(self) -> None:
+    super()._drop_workspaces()
+    self.__dict__.pop('_tables_ready', None)
+
   def process(self, luminance: torch.Tensor, detail: float) -> torch.Tensor:
     _require(luminance.dtype in (torch.float32, torch.float16), 'Input must be float32')
     _require(luminance.dim() == 2, 'Input must be 2D (H,W)')
@@ -675,9 +714,10 @@ class Bilateral(_Workspace):
     x = luminance.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      ws = self._workspace(lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
-      check(lib.tdk_bilateral(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
-                              _dtype_tag(x), _stream()))
+      # one buffer serves both entry points (the rgb layout is the larger one and starts with the same tables)
+      ws, flags = self._prepared_workspace(lib.tdk_bilateral_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      check(lib.tdk_bilateral_ex(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+                                 _dtype_tag(x), flags, _stream()))
     return out
 
   def _process_rgb(self, image: torch.Tensor, detail: float, log_mode: bool, eps: float, luminance: torch.Tensor | None = None,
@@ -687,15 +727,12 @@ class Bilateral(_Workspace):
     x = image.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      ws = self._workspace(lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
-      if luminance is None:
-        check(lib.tdk_bilateral_rgb(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
-                                    int(log_mode), float(eps), _dtype_tag(x), _stream()))
-      else:
+      ws, flags = self._prepared_workspace(lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), x.device)
+      if luminance is not None:
         _require(luminance.dtype == torch.float32 and luminance.is_contiguous() and luminance.device == x.device
                  and tuple(luminance.shape) == (self._height, self._width), 'luminance must be a contiguous float32 (H, W) tensor on the image device')
-        check(lib.tdk_bilateral_rgb_lum(_ptr(x), _ptr(luminance), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r,
-                                        float(detail), int(log_mode), float(eps), _dtype_tag(x), _stream()))
+      check(lib.tdk_bilateral_rgb_ex(_ptr(x), _ptr(luminance), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r,
+                                     float(detail), int(log_mode), float(eps), _dtype_tag(x), flags, _stream()))
     if metrics is not None:
       metrics.add(out)
     return out
