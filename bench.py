@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: megapixels/s of the full RAW ISP on synthetic 12 MP RGGB frames.
 
-  python bench.py --gpus N --steps K --warmup W [--workload isp|rcd] [--storage f16|f32]
+  python bench.py --gpus N --steps K --warmup W [--workload isp|rcd|ppg_wiener50] [--storage f16|f32]
 
 One step = one pass of the hot path over one batch of device-resident synthetic frames per GPU:
   isp (BASELINE.json configs[2], the configuration the metric is quoted on):
@@ -12,6 +12,8 @@ One step = one pass of the hot path over one batch of device-resident synthetic 
       reference torch_darktable/pipeline/config.py:114-146; "nlmeans" in BASELINE.json has no
       counterpart in the reference, its denoiser is the tiled-FFT Wiener filter)
   rcd (configs[1]): one 4096x3072 fp32 frame through RCD.process.
+  ppg_wiener50 (configs[4]): 4 x 8192x6144 RGGB per GPU, fp16 storage, PPG.process -> Wiener.process C=3 (K=32, ov=4,
+      sigma=0.05 as reference scripts/run_benchmark.py:96; the reference has no wavelet denoiser).
 The frames of a batch are independent; they are issued round-robin on --streams HIP streams (default 2), each with
 its own op workspaces, so one frame's kernel tails overlap the next frame's kernels.
 
@@ -25,9 +27,12 @@ used as they are.  The number of ranks that ran must equal --gpus or the run fai
 `n_gpus` different from `--gpus` cannot be printed.
 
 Prints ONE JSON line on rank 0 (contract in the task description): metric/value/unit...,
-"roofline" for the dominant kernel (per-kernel device time measured live with HIP events on the
-launch stream by the library's tdk_profile_* timer), and "cpu_baseline" (the strict-fp32 CPU
-oracle, i.e. a port -- the reference has no CPU path -- timed on a bounded sample).
+"roofline" for the dominant kernel = its HBM fraction: the algorithmic bytes of the stage it implements
+divided by its average launch time (measured live with HIP events on the launch stream by the library's tdk_profile_*
+timer) against 8 TB/s; the vector-ALU issue floors (which are what actually bound these kernels) are reported beside it
+under "valu" / "composite", never as `frac`; "cpu_baseline" (the strict-fp32 CPU oracle, i.e. a port -- the reference has
+no CPU path -- timed on a bounded sample) and "parity_check": the uint8 output of GPU frame 0 in the last timed step
+against the oracle's output for the same input.  Exit code 3 if that check fails.
 """
 
 from __future__ import annotations
@@ -53,11 +58,14 @@ sys.path.insert(0, str(ROOT))
 # and twice the plain cost for any VALU instruction with an SGPR / VCC source operand -- the floor below
 # uses the nominal 2 / 8 and is therefore optimistic.
 VALU_CUS, VALU_SIMDS, VALU_CLOCK_GHZ = 256, 4, 2.4
-VALU_CYCLES_PLAIN, VALU_CYCLES_TRANS = 2, 8
+VALU_CYCLES_PLAIN, VALU_CYCLES_TRANS, VALU_CYCLES_PACKED = 2, 8, 4
+# what the same instruction classes cost on the box (tests/hip_unit/valu_issue_bench.hip, pk_issue_bench.hip: DESIGN.md 3.0)
+VALU_MEASURED_PLAIN, VALU_MEASURED_TRANS, VALU_MEASURED_PACKED = 2.4, 8.5, 4.3
 VALU_PEAK_GINST = VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ / VALU_CYCLES_PLAIN
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 
 W12, H12 = 4096, 3072
+W50, H50 = 8192, 6144
 
 
 def parse_args(argv=None):
@@ -65,13 +73,14 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=['isp', 'rcd'], default='isp')
-    ap.add_argument('--storage', choices=['f16', 'f32'], default=None, help='image storage type (default: f16 for isp, f32 for rcd)')
-    ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 8 for isp, 1 for rcd)')
+    ap.add_argument('--workload', choices=['isp', 'rcd', 'ppg_wiener50'], default='isp')
+    ap.add_argument('--storage', choices=['f16', 'f32'], default=None, help='image storage type (default: f32 for rcd, f16 otherwise)')
+    ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 8 for isp, 1 for rcd, 4 for ppg_wiener50)')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
-    ap.add_argument('--width', type=int, default=W12)
-    ap.add_argument('--height', type=int, default=H12)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--width', type=int, default=None)
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle run (and with it the parity check)')
+    ap.add_argument('--pin-cpus', action='store_true', help='self-launched ranks: give each rank its own slice of the host cores (os.sched_setaffinity)')
     ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-kernel event timer off in the timed region')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='REHEARSAL ONLY (tests/test_bench_launch.py): run the rank/launch/timing protocol on the CPU with a stand-in '
@@ -88,6 +97,24 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def cpu_slices(n: int) -> list[list[int]]:
+    """The host cores this process may run on, cut into n contiguous slices (rank r issues its ~1 000 launches per step from
+    its own cores: no rank's launch thread migrates onto another's).  Contiguous core numbers share a socket / NUMA node on
+    the usual enumeration; the GPU -> NUMA affinity itself is not visible without root tools, so none is assumed."""
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // n)
+    return [cores[(r * per) % len(cores):(r * per) % len(cores) + per] for r in range(n)]
+
+
+def pin_self() -> list[int] | None:
+    spec = os.environ.get('TDK_BENCH_CPUS')
+    if not spec:
+        return None
+    cpus = [int(c) for c in spec.split(',')]
+    os.sched_setaffinity(0, cpus)
+    return cpus
+
+
 def launch_ranks(args, argv) -> int:
     """Parent of a self-launched multi-GPU run.  Starts args.gpus children of this script (one per
     GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment), waits for all of them, relays
@@ -102,8 +129,11 @@ def launch_ranks(args, argv) -> int:
     env.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'TDK_BENCH_SELF_LAUNCHED': '1'})
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     procs = []
+    slices = cpu_slices(n) if args.pin_cpus else [None] * n
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        if slices[r]:
+            e['TDK_BENCH_CPUS'] = ','.join(map(str, slices[r]))  # the child pins itself before it starts any thread (pin_self)
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, _ = procs[0].communicate()
@@ -175,35 +205,37 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-# Algorithmic (compulsory) bytes per pixel of each kernel family at its op boundary:
-# (bytes in + bytes out) with s = bytes per stored sample (2 for f16, 4 for f32).  SURVEY.md 8(d).
-def algorithmic_bytes_per_px(kernel: str, s: int) -> float | None:
-    table = {
-        'tdk_rcd': 1 * s + 3 * s,                    # bayer in, rgb out
-        # on the fused Wiener.process_log_luminance path the op boundary is RGB in, RGB out (the
-        # log-luminance planes are internal): SURVEY.md 8(d) "denoise 6 + 6 = 12 B/px" at fp16
-        'tdk_wiener(tiles)': 3 * s + 3 * s,
-        'tdk_wiener(finish)': 1 * s + 1 * s,
-        'tdk_wiener(finish+modify)': 3 * s + 3 * s,
-        'tdk_bilateral(slice+modify)': 3 * s + 3 * s,
-        'tdk_bilateral(tiles)': 3 * s + 3 * s,       # fused op on the process_rgb path: RGB in, RGB out
-        'tdk_bilateral(splat)': 1 * s + 1 * s,       # the bilateral op on one plane
-        'tdk_bilateral(blur_xy)': 1 * s + 1 * s,
-        'tdk_bilateral(blur_z)': 1 * s + 1 * s,
-        'tdk_bilateral(slice)': 1 * s + 1 * s,
-        'tdk_compute_luminance': 3 * s + 1 * s,
-        'tdk_modify_luminance': 3 * s + 1 * s + 3 * s,
-        'tdk_tonemap': 3 * s + 3,
-        'tdk_image_metrics_accumulate': 0.0,
-    }
-    return table.get(kernel)
+# algorithmic bytes per pixel of each NAMED STAGE at the Python-wrapper boundary (s = bytes per stored sample:
+# 2 for f16, 4 for f32) and the kernels that implement the stage.  roofline.achieved prices the dominant kernel on the bytes of
+# ITS stage (what the stage has to move, whatever the kernel split inside it).
+def stages(workload: str, s: int):
+    if workload == 'isp':
+        return {
+            'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(border)']),
+            'denoise': (3 * s + 3 * s, ['tdk_compute_luminance', 'tdk_wiener(tiles)', 'tdk_wiener(finish+modify)']),
+            'local_contrast': (3 * s + 3 * s, ['tdk_bilateral(tiles)', 'tdk_bilateral(tables)', 'tdk_bilateral(slice+modify)', 'tdk_bilateral(splat)',
+                                                'tdk_bilateral(blur_xy)', 'tdk_bilateral(blur_z)']),
+            'tonemap': (3 * s + 3, ['tdk_image_metrics_accumulate', 'tdk_image_metrics_finish', 'tdk_tonemap']),
+        }
+    if workload == 'rcd':
+        return {'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(border)'])}
+    return {'debayer': (1 * s + 3 * s, ['tdk_ppg', 'tdk_ppg(pre_median)']),
+            'denoise': (3 * s + 3 * s, ['tdk_wiener(tiles)', 'tdk_wiener(finish)'])}
 
 
-# Bytes ONE LAUNCH of a kernel has to move per pixel (its own compulsory reads + writes; s = bytes per stored sample):
-# what the kernel's HBM time is priced on.  The op-boundary numbers above are what the Python-wrapper stage would move.
+def stage_of(kernel: str, workload: str, s: int):
+    for name, (bpp, kernels) in stages(workload, s).items():
+        if kernel in kernels:
+            return name, bpp
+    return None, None
+
+
+# Bytes ONE LAUNCH of a kernel has to move per pixel (its own compulsory reads + writes): what the composite floor prices a
+# kernel's HBM time on.
 def launch_bytes_per_px(kernel: str, s: int) -> float | None:
     table = {
         'tdk_rcd': 1 * s + 3 * s,
+        'tdk_ppg': 1 * s + 3 * s,
         'tdk_compute_luminance': 3 * s + 4,                    # RGB in, fp32 (log-)lightness plane out
         'tdk_wiener(tiles)': 4 + 4,                            # fp32 plane in, the denoised plane's sums out (fp32 slabs)
         'tdk_wiener(finish+modify)': 4 + 3 * s + 3 * s + 4,    # sums in, RGB in, RGB out, fp32 lightness of the result out
@@ -213,15 +245,32 @@ def launch_bytes_per_px(kernel: str, s: int) -> float | None:
         'tdk_image_metrics_accumulate': 3 * s / 64.0,          # stride-8 sample grid
         'tdk_image_metrics_finish': 0.0,
         'tdk_rcd(border)': 0.0,                                # the 7-px ring: its bytes are in tdk_rcd's boundary count
-        'tdk_bilateral(tables)': 0.0,                          # per-launch axis tables, a few hundred KB
+        'tdk_bilateral(tables)': 0.0,                          # axis tables, a few hundred KB, once per workspace
     }
     return table.get(kernel)
+
+
+def csrc_sha() -> str:
+    """Content hash of the kernel sources: profiles/collect_traffic.py stores it with the counters it captures, and the counters
+    are only used for a floor when they were captured from these very sources."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / 'torch-darktable_amd' / 'csrc').glob('*')):
+        if f.suffix in ('.hip', '.h'):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def build_pipeline(td, dev, w, h, storage, workload):
     import torch
 
     dtype = torch.float16 if storage == 'f16' else torch.float32
+    if workload == 'ppg_wiener50':
+        ppg = td.PPG(dev, (w, h), td.BayerPattern.RGGB)
+        wiener3 = td.Wiener(dev, (w, h), overlap_factor=4, tile_size=32)
+        return dtype, lambda bayer: wiener3.process(ppg.process(bayer), 0.05)
     rcd = td.RCD(dev, (w, h), td.BayerPattern.RGGB)
     if workload == 'rcd':
         return dtype, lambda bayer: rcd.process(bayer)
@@ -245,10 +294,13 @@ def build_pipeline(td, dev, w, h, storage, workload):
     return dtype, frame
 
 
-def cpu_baseline(workload, threads, budget_s=25.0):
+def cpu_baseline(workload, threads, frame0, budget_s=25.0):
     """The oracle chain (a CPU port: the reference has no CPU path) on a bounded sample: full
     4096x3072 frames, one warm-up on a quarter-size frame, then timed
-    full-size runs until three are done or the time budget is spent (at least one)."""
+    full-size runs until three are done or the time budget is spent (at least one).  frame0 = the very samples GPU frame 0
+    of rank 0 holds (copied back after the timed region, as float32; the device generator's noise differs from the CPU
+    generator's, so the frame cannot be re-made on the host), or None: a host-made frame of the same kind.  The last
+    result is returned for the parity check."""
     import numpy as np
 
     sys.path.insert(0, str(ROOT / 'oracle'))
@@ -259,6 +311,8 @@ def cpu_baseline(workload, threads, budget_s=25.0):
     O.build()
 
     def run(bayer):
+        if workload == 'ppg_wiener50':
+            return O.wiener(O.ppg(bayer[:, :, 0] if bayer.ndim == 3 else bayer, O.RGGB), [0.05, 0.05, 0.05], 32, 4)
         rgb = O.rcd(bayer, O.RGGB)
         if workload == 'rcd':
             return rgb
@@ -268,19 +322,41 @@ def cpu_baseline(workload, threads, budget_s=25.0):
         m = O.image_metrics([rgb], 8)
         return O.tonemap('reinhard', rgb, m, 0.75, 2.0, 1.0, 0.0)
 
-    run(synthetic_bayer(H12 // 2, W12 // 2, seed=1234, device='cpu').numpy())  # warm-up (page-in, OpenMP pool)
-    bayer = synthetic_bayer(H12, W12, seed=1234, device='cpu').numpy()
-    times, t_start = [], time.perf_counter()
+    # the CPU sample is a 12 MP frame for every workload (50 MP through the oracle takes minutes)
+    bayer = frame0 if frame0 is not None and frame0.shape[:2] == (H12, W12) else synthetic_bayer(H12, W12, seed=1234, device='cpu').numpy()
+    run(np.ascontiguousarray(bayer[:H12 // 2, :W12 // 2]))  # warm-up (page-in, OpenMP pool)
+    times, t_start, result = [], time.perf_counter(), None
     while len(times) < 3 and (not times or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
-        run(bayer)
+        result = run(bayer)
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
     return {
         'value': round(W12 * H12 / 1e6 / dt, 3), 'unit': 'MP/s', 'cores': threads, 'kind': 'port',
         'sample': f'median of {len(times)} x one {W12}x{H12} RGGB frame through the strict-fp32 C oracle of the same chain (OpenMP, {threads} threads), '
-                  'after one warm-up on a 2048x1536 frame; fp32 storage (the oracle has no fp16 mode)',
-    }
+                  'after one warm-up on a 2048x1536 crop; fp32 arithmetic on the samples GPU frame 0 read (the oracle has no fp16 storage mode)',
+    }, result
+
+
+def parity_check(workload, gpu_out, oracle_out):
+    """GPU frame 0 of the last timed step against the oracle's result for the same input.  isp: uint8 output, bound = the
+    one of tests/test_gpu_fullsize.py::test_full_pipeline_12mp_fp16_vs_fp32_oracle (+-2 LSB, > 1 LSB on < 1 % of the values);
+    rcd (fp32 storage): bit-exact."""
+    import numpy as np
+
+    got = gpu_out.cpu().numpy()
+    if got.shape != oracle_out.shape:
+        return {'ok': None, 'skipped': f'shapes differ: GPU {got.shape}, oracle sample {oracle_out.shape} (the CPU sample of this workload is not the GPU frame)'}
+    if workload == 'isp':
+        d = np.abs(got.astype(np.int32) - oracle_out.astype(np.int32))
+        res = {'max_lsb': int(d.max()), 'frac_gt_1lsb': float((d > 1).mean()), 'frac_ne': float((d > 0).mean()),
+               'bound': 'max_lsb <= 2 and frac_gt_1lsb < 1e-2 (fp16 storage of three intermediates against the fp32 oracle)'}
+        res['ok'] = bool(res['max_lsb'] <= 2 and res['frac_gt_1lsb'] < 1e-2)
+        return res
+    if workload == 'rcd':
+        bad = int((got != oracle_out.astype(got.dtype)).sum())
+        return {'mismatches': bad, 'bound': 'bit-exact', 'ok': bad == 0}
+    return {'ok': None, 'skipped': 'no full-frame oracle sample for this workload'}
 
 
 def _git_head() -> str | None:
@@ -295,7 +371,7 @@ def _git_head() -> str | None:
     return head or None
 
 
-def run_stub(args, ranks: Ranks):
+def run_stub(args, ranks: Ranks, pinned=None):
     """CPU rehearsal of the rank protocol (no HIP): same warm-up / barrier / timed region / max-over-ranks
     / one JSON line, with a pure-torch stand-in stage.  Used by tests/test_bench_launch.py only."""
     import torch
@@ -303,7 +379,7 @@ def run_stub(args, ranks: Ranks):
     from torch_darktable.synthetic import synthetic_bayer
 
     frames = args.frames or 2
-    w, h = min(args.width, 64), min(args.height, 64)
+    w, h = min(args.width or 64, 64), min(args.height or 64, 64)
     inputs = [synthetic_bayer(h, w, seed=1234 + ranks.rank * frames + i, device='cpu') for i in range(frames)]
 
     def step():
@@ -318,6 +394,7 @@ def run_stub(args, ranks: Ranks):
     elapsed = time.perf_counter() - t0
     ranks.barrier()
     per_rank = ranks.gather(elapsed)
+    ncpus = ranks.gather(float(len(os.sched_getaffinity(0))))
     if ranks.rank == 0:
         assert len(per_rank) == args.gpus
         worst = max(per_rank)
@@ -327,6 +404,7 @@ def run_stub(args, ranks: Ranks):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'stub',
             'config': {'workload': 'stub', 'frames_per_gpu_per_step': frames}, 'ranks_ran': len(per_rank),
             'per_rank_MPps': [round(frames * args.steps * w * h / 1e6 / t, 3) for t in per_rank],
+            'cpus_per_rank': [int(c) for c in ncpus], 'pinned': bool(pinned),
         }))
     ranks.close()
 
@@ -340,9 +418,10 @@ def main(argv=None):
         # no launcher: start the N ranks ourselves, BEFORE anything in this process touches the GPU
         return launch_ranks(args, argv)
 
+    pinned = pin_self()
     ranks = Ranks(args)
     if args.stub_cpu:
-        run_stub(args, ranks)
+        run_stub(args, ranks, pinned)
         return 0
 
     import torch
@@ -362,9 +441,9 @@ def main(argv=None):
     from torch_darktable import _native
     from torch_darktable.synthetic import synthetic_bayer
 
-    storage = args.storage or ('f16' if args.workload == 'isp' else 'f32')
-    frames = args.frames or (8 if args.workload == 'isp' else 1)
-    w, h = args.width, args.height
+    storage = args.storage or ('f32' if args.workload == 'rcd' else 'f16')
+    frames = args.frames or {'isp': 8, 'rcd': 1, 'ppg_wiener50': 4}[args.workload]
+    w, h = (args.width or (W50 if args.workload == 'ppg_wiener50' else W12)), (args.height or (H50 if args.workload == 'ppg_wiener50' else H12))
     # The frames of a batch are independent: they are issued round-robin on `nstreams` HIP streams, each with its own
     # op workspaces, so that the tail of one frame's kernels (partially filled last rounds, 1-workgroup finish kernels)
     # overlaps the next frame's -- measured +13 % at 2-3 streams (profiles/streams_exp.py).
@@ -384,8 +463,10 @@ def main(argv=None):
             out = process(b)
         return out
 
+    last = [None]
+
     def step():  # the timed region synchronises the device after its K steps, so the streams are not joined per step
-        return runner.issue(inputs)[-1]
+        last[0] = runner.issue(inputs)
 
     for _ in range(args.warmup):
         step()
@@ -437,83 +518,106 @@ def main(argv=None):
         stage_ms = {k: round(ms / frames, 4) for k, (c, ms) in sorted(table.items(), key=lambda kv: -kv[1][1])}  # from the untimed pass
         cnt, ms = report[dom]  # the dominant kernel, timed live in the timed region
         avg_s = ms / cnt / 1e3
-        lbpp = launch_bytes_per_px(dom, sbytes) or algorithmic_bytes_per_px(dom, sbytes)
-        op_bpp = algorithmic_bytes_per_px(dom, sbytes)
-        achieved = (lbpp * w * h / avg_s / 1e9) if lbpp else None
-        hbm_time_s = lbpp * w * h / (HBM_PEAK_GBS * 1e9) if lbpp else None
-        captured, valu, composite = None, None, None
+        alone_s = table[dom][1] / table[dom][0] / 1e3  # the same kernel with the GPU to itself (untimed serial pass)
+        stage, stage_bpp = stage_of(dom, args.workload, sbytes)
+        planes = 3 if (args.workload == 'ppg_wiener50' and dom.startswith('tdk_wiener')) else 1  # C = 3: one launch covers the three planes
+        alg_bytes = stage_bpp * w * h if stage_bpp else None
+        achieved = alg_bytes / avg_s / 1e9 if alg_bytes else None
+        lbpp = launch_bytes_per_px(dom, sbytes)
+        stage_kernels = stages(args.workload, sbytes)[stage][1] if stage else []
+        stage_us = sum(table[k][1] / frames * 1e3 for k in stage_kernels if k in table)  # per frame, GPU to itself
+        captured, valu, composite, why_not = None, None, None, None
         tfile = ROOT / 'profiles' / 'traffic.json'  # written by profiles/collect_traffic.py from rocprofv3 --pmc passes
-        if tfile.exists() and (w, h, storage, args.workload) == (W12, H12, 'f16', 'isp'):
+        if not tfile.exists():
+            why_not = 'profiles/traffic.json missing'
+        elif (w, h, storage, args.workload) != (W12, H12, 'f16', 'isp'):
+            why_not = 'the counters in profiles/traffic.json were captured on the isp workload at 12 MP fp16'
+        else:
             tj = json.loads(tfile.read_text())
-
-            def alu_floor_s(kernel):
-                """Issue floor of one launch from the captured counters: plain wave64 instructions 2 SIMD cycles, packed fp32
-                (two operations per lane) 4, transcendentals 8."""
+            if tj.get('_csrc_sha') != csrc_sha():
+                why_not = (f"profiles/traffic.json was captured from other kernel sources (its csrc hash {tj.get('_csrc_sha')}, git {tj.get('_git')}; "
+                           f'these sources {csrc_sha()}): counters not used')
+                tj = None
+        if why_not is None:
+            def alu_floor_s(kernel, plain=VALU_CYCLES_PLAIN, trans=VALU_CYCLES_TRANS, packed=VALU_CYCLES_PACKED):
+                """Issue floor of one launch from the captured counters: cycles per wave64 instruction by class."""
                 insts = tj.get('_valu', {}).get(kernel)
                 if not insts:
                     return None
-                trans, packed = tj.get('_trans', {}).get(kernel) or 0, tj.get('_packed', {}).get(kernel) or 0
-                cyc = insts * VALU_CYCLES_PLAIN + trans * (VALU_CYCLES_TRANS - VALU_CYCLES_PLAIN) + packed * VALU_CYCLES_PLAIN
+                n_trans, n_packed = tj.get('_trans', {}).get(kernel) or 0, tj.get('_packed', {}).get(kernel) or 0
+                cyc = (insts - n_trans - n_packed) * plain + n_trans * trans + n_packed * packed
                 return cyc / (VALU_CUS * VALU_SIMDS * VALU_CLOCK_GHZ * 1e9)
 
-            captured = {'hbm_bytes_per_launch': tj.get(dom), 'git': tj.get('_git'), 'source': 'profiles/traffic.json (rocprofv3 --pmc passes, not this run)'}
+            measured = dict(plain=VALU_MEASURED_PLAIN, trans=VALU_MEASURED_TRANS, packed=VALU_MEASURED_PACKED)
+            captured = {'hbm_bytes_per_launch': tj.get(dom), 'git': tj.get('_git'), 'csrc_sha': tj.get('_csrc_sha'),
+                        'source': 'profiles/traffic.json (rocprofv3 --pmc passes of these kernel sources, not this run)'}
             floor_s = alu_floor_s(dom)
             if floor_s:
                 valu = {'wave_insts_per_launch': tj['_valu'][dom], 'transcendental_insts_per_launch': tj.get('_trans', {}).get(dom),
                         'packed_fp32_insts_per_launch': tj.get('_packed', {}).get(dom),
                         'achieved_Ginst_per_s': round(tj['_valu'][dom] / avg_s / 1e9, 1), 'peak_Ginst_per_s': round(VALU_PEAK_GINST, 1),
-                        'alu_floor_us': round(floor_s * 1e6, 2), 'issue_frac': round(floor_s / avg_s, 4), 'counters_captured_at_git': tj.get('_git')}
+                        'alu_floor_us': round(floor_s * 1e6, 2), 'alu_floor_measured_us': round(alu_floor_s(dom, **measured) * 1e6, 2),
+                        'issue_frac': round(floor_s / avg_s, 4), 'issue_frac_measured': round(alu_floor_s(dom, **measured) / avg_s, 4),
+                        'prices': {'nominal_cycles': [VALU_CYCLES_PLAIN, VALU_CYCLES_PACKED, VALU_CYCLES_TRANS],
+                                   'measured_cycles': [VALU_MEASURED_PLAIN, VALU_MEASURED_PACKED, VALU_MEASURED_TRANS], 'order': 'plain, packed fp32, transcendental'}}
             # composite floor of the whole frame: every kernel at the larger of its HBM time and its issue floor
-            comp_us, parts = 0.0, {}
+            comp_us, comp_m_us, parts = 0.0, 0.0, {}
             for k, (c, ms_k) in table.items():
                 kb = launch_bytes_per_px(k, sbytes)
                 t_hbm = (kb * w * h / (HBM_PEAK_GBS * 1e9)) if kb else 0.0
-                t_alu = alu_floor_s(k) or 0.0
-                per_frame = max(t_hbm, t_alu) * c / frames
-                parts[k] = {'hbm_us': round(t_hbm * 1e6, 1), 'alu_floor_us': round(t_alu * 1e6, 1), 'measured_us': round(ms_k / c * 1e3, 1), 'launches_per_frame': c / frames}
-                comp_us += per_frame * 1e6
+                t_alu, t_alu_m = alu_floor_s(k) or 0.0, alu_floor_s(k, **measured) or 0.0
+                parts[k] = {'hbm_us': round(t_hbm * 1e6, 1), 'alu_floor_us': round(t_alu * 1e6, 1), 'alu_floor_measured_us': round(t_alu_m * 1e6, 1),
+                            'measured_us': round(ms_k / c * 1e3, 1), 'launches_per_frame': c / frames}
+                comp_us += max(t_hbm, t_alu) * c / frames * 1e6
+                comp_m_us += max(t_hbm, t_alu_m) * c / frames * 1e6
             frame_us = elapsed / (frames * args.steps) * 1e6
-            composite = {'composite_floor_us_per_frame': round(comp_us, 1), 'measured_us_per_frame': round(frame_us, 1),
-                         'frac_of_composite': round(comp_us / frame_us, 4), 'kernels': parts,
-                         'note': 'sum over the kernels of a frame of max(HBM time of the launch bytes at 8 TB/s, issue floor from the captured counters)'}
-        bound = 'hbm'
-        frac = round(achieved / HBM_PEAK_GBS, 5) if achieved else None
-        if valu and hbm_time_s and valu['alu_floor_us'] * 1e-6 > hbm_time_s:
-            bound, frac = 'valu', valu['issue_frac']  # the kernel cannot go faster than its instruction issue: that is its roofline
-        alone_s = table[dom][1] / table[dom][0] / 1e3
+            composite = {'composite_floor_us_per_frame': round(comp_us, 1), 'composite_floor_measured_prices_us_per_frame': round(comp_m_us, 1),
+                         'measured_us_per_frame': round(frame_us, 1), 'frac_of_composite': round(comp_us / frame_us, 4),
+                         'frac_of_composite_measured': round(comp_m_us / frame_us, 4), 'kernels': parts,
+                         'note': 'sum over the kernels of a frame of max(HBM time of the launch bytes at 8 TB/s, issue floor from the captured '
+                                 'counters); the second pair prices the instructions at what they cost on the box'}
         roofline = {
-            'kernel': dom, 'bound': bound, 'frac': frac,
-            'frac_means': ('vector-ALU issue floor / measured launch time (the HBM figures follow as hbm_*)' if bound == 'valu'
-                           else 'achieved / peak HBM bandwidth on the bytes this launch has to move'),
+            'kernel': dom, 'bound': 'hbm', 'frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+            'frac_means': f"SURVEY.md 8(d) bytes of the '{stage}' stage ({stage_bpp} B/px x {w}x{h}) / this kernel's average launch time / 8 TB/s",
             'achieved': round(achieved, 2) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'hbm_frac': round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-            'algorithmic_bytes_per_launch': int(lbpp * w * h) if lbpp else None,
-            'op_boundary_bytes_per_launch': int(op_bpp * w * h) if op_bpp else None,
-            'traffic': captured['hbm_bytes_per_launch'] if captured else None, 'traffic_captured': captured,
+            'algorithmic_bytes_per_launch': int(alg_bytes) if alg_bytes else None, 'planes_per_launch': planes,
+            'traffic': captured['hbm_bytes_per_launch'] if captured else None, 'traffic_captured': captured, 'traffic_unavailable': why_not,
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches': cnt,
-            # the same kernel with the GPU to itself (untimed serial pass): in the timed region frames on the other stream(s) share the CUs with it
+            # the same kernel with the GPU to itself: in the timed region frames on the other stream(s) share the CUs with it
             'avg_launch_us_alone': round(alone_s * 1e6, 2),
-            'hbm_frac_alone': round(lbpp * w * h / alone_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None,
-            'frac_alone': (round(valu['alu_floor_us'] * 1e-6 / alone_s, 4) if bound == 'valu'
-                           else (round(lbpp * w * h / alone_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None)),
-            'kernel_launches_in_timed_region': launches_total, 'valu': valu, 'composite': composite,
+            'frac_alone': round(alg_bytes / alone_s / 1e9 / HBM_PEAK_GBS, 5) if alg_bytes else None,
+            # the kernel's own compulsory bytes (it is one of several kernels of its stage)
+            'launch_bytes': int(lbpp * w * h) if lbpp else None,
+            'launch_bytes_frac': round(lbpp * w * h / avg_s / 1e9 / HBM_PEAK_GBS, 5) if lbpp else None,
+            # the whole stage the kernel belongs to, per frame, kernels back to back
+            'stage': {'name': stage, 'kernels': [k for k in stage_kernels if k in table], 'us_per_frame_alone': round(stage_us, 1),
+                      'frac': round(alg_bytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if alg_bytes and stage_us else None},
+            'kernel_launches_in_timed_region': launches_total, 'launches_per_frame': round(launches_total / (args.steps * frames), 2),
+            'valu': valu, 'composite': composite,
         }
-    # whole-pipeline roofline at the Python-wrapper stage boundaries (SURVEY.md 8(d): 41 B/px f16, 79 B/px f32; RCD only: 4*s B/px)
-    pipe_bpp = (41 if storage == 'f16' else 79) if args.workload == 'isp' else 4 * sbytes
+    # whole-pipeline roofline at the Python-wrapper stage boundaries (SURVEY.md 8(d): isp 41 B/px f16, 79 B/px f32; RCD 4 s; config 5 10 s)
+    pipe_bpp = sum(b for b, _ in stages(args.workload, sbytes).values())
     pipe_gbs = pipe_bpp * w * h * total_frames / world / elapsed / 1e9
 
+    metric = {'isp': 'megapixels/sec full ISP (debayer->denoise->tonemap) 12MP RGGB', 'rcd': 'megapixels/sec RCD demosaic 12MP RGGB',
+              'ppg_wiener50': 'megapixels/sec PPG demosaic + Wiener C=3 denoise 50MP RGGB'}[args.workload]
+    workload_text = {
+        'isp': ('12 MP full pipeline (RCD -> Wiener log-L sigma=0.075 K=32 ov=4 -> bilateral sigma_s=2 sigma_r=0.2 detail=0.4 -> '
+                'metrics -> Reinhard gamma=0.75 intensity=2 light_adapt=1 -> u8), batch 8 per GPU'),
+        'rcd': '12 MP RCD demosaic, single frame',
+        'ppg_wiener50': '50 MP PPG demosaic -> Wiener.process C=3 sigma=0.05 K=32 ov=4 (BASELINE config 5; the reference has no wavelet denoiser), batch 4 per GPU',
+    }[args.workload]
     out = {
-        'metric': 'megapixels/sec full ISP (debayer->denoise->tonemap) 12MP RGGB' if args.workload == 'isp' else 'megapixels/sec RCD demosaic 12MP RGGB',
+        'metric': metric,
         'value': round(value, 2), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': ('12 MP full pipeline (RCD -> Wiener log-L sigma=0.075 K=32 ov=4 -> bilateral sigma_s=2 sigma_r=0.2 detail=0.4 -> '
-                         'metrics -> Reinhard gamma=0.75 intensity=2 light_adapt=1 -> u8), batch 8 per GPU') if args.workload == 'isp'
-                        else '12 MP RCD demosaic, single frame',
+            'workload': workload_text,
             'width': w, 'height': h, 'frames_per_gpu_per_step': frames, 'streams_per_gpu': nstreams, 'storage': storage, 'arithmetic': 'f32',
-            'denoiser': 'Wiener (the reference has no nlmeans)', 'sharding': 'independent frames per GPU, no collective (gloo barrier + max of the timing only)'
+            'denoiser': 'Wiener (the reference has no nlmeans / wavelet denoiser)', 'sharding': 'independent frames per GPU, no collective (gloo barrier + max of the timing only)'
             + (' -- REHEARSAL: ranks share GPUs (TDK_BENCH_SHARE_GPU=1), not a scaling measurement' if shared else ''),
+            'cpus_pinned': pinned,
         },
         'ranks_ran': len(per_rank),
         'per_rank_MPps': [round(frames * args.steps * mp_per_frame / t, 1) for t in per_rank],
@@ -524,14 +628,23 @@ def main(argv=None):
                                       'timed live in the timed region (where frames on other streams share the GPU with it)',
         'git': _git_head(),
     }
+    rc = 0
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out['cpu_baseline'] = cpu_baseline(args.workload, os.cpu_count() or 1)
+            frame0 = inputs[0].float().cpu().numpy()  # what GPU frame 0 read (binary16 values for fp16 storage), after the timed region
+            out['cpu_baseline'], oracle_out = cpu_baseline(args.workload, os.cpu_count() or 1, frame0)
+            out['parity_check'] = parity_check(args.workload, last[0][0], oracle_out) if (w, h) == (W12, H12) else {
+                'ok': None, 'skipped': 'the CPU sample is a 12 MP frame; this run used another size'}
+            out['parity_check']['what'] = 'GPU frame 0 of the last timed step (seed 1234) against the CPU oracle on the same input'
+            if out['parity_check'].get('ok') is False:
+                print(f"bench.py: PARITY CHECK FAILED: {out['parity_check']}", file=sys.stderr)
+                rc = 3
         except Exception as e:  # noqa: BLE001
             out['cpu_baseline'] = {'value': None, 'unit': 'MP/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {e}'}
+            out['parity_check'] = {'ok': None, 'skipped': f'oracle run failed: {e}'}
     print(json.dumps(out))
     ranks.close()
-    return 0
+    return rc
 
 
 if __name__ == '__main__':

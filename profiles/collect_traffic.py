@@ -119,7 +119,14 @@ def main():
     pshare = static_trans_share('packed')   # packed fp32 (two operations per lane, 4 SIMD cycles): static share x SQ_INSTS_VALU
     packed_named = {KERNELS[k][0]: int(v * pshare[k]) for k, v in valu.items() if pshare.get(k)}
     sq_named = {c: {KERNELS[k][0]: round(v, 1) for k, v in per.items()} for c, per in sq.items()}
+    import hashlib
+    h = hashlib.sha256()   # content hash of the kernel sources the counters belong to (bench.py csrc_sha): a capture is only
+    for f in sorted((Path(__file__).resolve().parent.parent / 'torch-darktable_amd' / 'csrc').glob('*')):  # used for these sources
+        if f.suffix in ('.hip', '.h'):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
     json.dump({**result, '_valu': valu_named, '_trans': trans_named, '_packed': packed_named, '_sq': sq_named, '_detail': detail, '_git': git,
+               '_csrc_sha': h.hexdigest()[:16],
                '_note': 'HBM-side bytes per launch; see profiles/collect_traffic.py for the corrections'}, open(out, 'w'), indent=1)
     print(json.dumps(result, indent=1))
 

@@ -78,3 +78,15 @@ def test_gpus8_rehearsal_eight_ranks():
     assert out['n_gpus'] == 8 and out['ranks_ran'] == 8 and len(out['per_rank_MPps']) == 8
     assert out['scaling'] == 'weak' and out['value'] <= sum(out['per_rank_MPps']) * (1 + 1e-3)
     assert r.stdout.count('{') >= 1 and len(_json_lines(r.stdout)) == 1  # no rank but 0 prints a line
+
+
+def test_gpus8_rehearsal_with_pinned_ranks():
+    """--pin-cpus: the parent cuts the host cores it may use into one slice per rank and every child pins itself to its slice
+    before it starts a thread; the line reports the cores each rank ended up with (8 ranks on this container's 8 cores: one
+    each) -- rank r's launch thread cannot migrate onto another rank's core."""
+    r = _run(['--gpus', '8', '--pin-cpus'], env_extra={'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr
+    (out,) = _json_lines(r.stdout)
+    ncores = len(os.sched_getaffinity(0))
+    assert out['ranks_ran'] == 8 and out['pinned'] is True
+    assert out['cpus_per_rank'] == [max(1, ncores // 8)] * 8
