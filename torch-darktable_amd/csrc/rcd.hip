@@ -92,6 +92,20 @@ template <bool FAST, int N> __device__ __forceinline__ void div_signed(const flo
   for (int i = 0; i < N; i++) q[i] = a[i] / b[i];
 }
 
+// the same with the wave's test made on a value the caller has prepared: mn = the smallest numerator magnitude of the lane's
+// quotients that anything reads (1 where nothing does)
+template <bool FAST, int N> __device__ __forceinline__ void div_signed_min(const float (&a)[N], const float (&b)[N], float (&q)[N], float mn) {
+  if constexpr (FAST) {
+    if (__builtin_amdgcn_ballot_w64(!(mn >= tdk::DIV_CORE_MIN_NUM)) == 0) {
+#pragma unroll
+      for (int i = 0; i < N; i++) q[i] = tdk::div_core(a[i], b[i]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = a[i] / b[i];
+}
+
 // v_diff / h_diff of the raw image at (fr, fc), or 0 outside step 1.1's range (rcd.cu:63-75)
 template <typename T>
 __device__ float diff_1_1(const T* __restrict__ in, int fr, int fc, int w, int h, bool vertical) {
@@ -649,6 +663,12 @@ __device__ __forceinline__ bool load_tile(const TI* __restrict__ in, int w, int 
 }
 
 #include "tdk_rcd_stream.h"
+#ifdef TDK_EXPERIMENTS
+// the register-blocked strips (a lane owns four columns, own-column 16-byte LDS reads, neighbour taps by DPP): bit-exact on
+// every RCD test, 55 % fewer LDS and 6 % fewer VALU instructions than rs::rcd_stream -- and 12 % slower (183 against 164 us),
+// because half-wave rows leave 12 instead of 24 waves per CU in the same LDS (profiles/r04/experiments/rcd_quad.txt).
+#include "tdk_rcd_quad.h"
+#endif
 
 // Persistent workgroups (one per CU: the five planes fill its LDS).  Work list: `nborder` chunks of the border
 // ring (independent of the tiles: disjoint output pixels, input read-only), then the tiles; workgroup b takes
@@ -728,13 +748,21 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       if (seg_rows > h) seg_rows = nsegs == 1 ? h : (h & ~1);
       nsegs = tdk_div_up(h, seg_rows);
       const int nwg = nstrips * nsegs;
-      const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
-      if (rc != TDK_OK) return rc;
       const int nbx = tdk_div_up(w, RING_LEN), nby = tdk_div_up(h - 14, RING_LEN);  // ring pieces: a share of the strip workgroups takes one each
       size_t strip_lds = rs::LDS_BYTES;
 #ifdef TDK_EXPERIMENTS
       if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
 #endif
+#ifdef TDK_EXPERIMENTS
+      if (getenv("TDK_RCD_QUAD")) {
+        const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+        if (rcq != TDK_OK) return rcq;
+        TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<TI, T>), dim3((unsigned)nwg), dim3(rq::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+        return TDK_OK;
+      }
+#endif
+      const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+      if (rc != TDK_OK) return rc;
       TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
       return TDK_OK;
     }

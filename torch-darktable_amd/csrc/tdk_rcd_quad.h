@@ -1,0 +1,530 @@
+// tdk_rcd_quad.h -- RCD column strips, register-blocked: a lane owns FOUR adjacent columns of a row (round 4).
+// Included by rcd.hip inside its anonymous namespace, after tdk_rcd_stream.h (shares its plane geometry, lags, border-rule
+// helpers and slide; div_pos / div_signed, Range, stale_diff, ring_piece come from rcd.hip).
+//
+// Same nine steps, the same expressions and the same schedule as rs::rcd_stream (reference csrc/debayer/rcd.cu:63-282): a
+// workgroup owns a strip of 108 output columns (128 computed), walks DOWN the frame 8 rows per step, every step runs its
+// vertical tap reach behind the newest CFA row on sliding linear LDS planes.  What changes is who reads what:
+//  * rs: wave = row, lane = column PAIR, planes de-interleaved by column parity; every tap is its own 4-byte LDS read (148 per
+//    lane and step, 74 per pixel).  Round 4's counters (profiles/r04/rcd_pmc_*.txt): LDS instructions active 70 % of the
+//    kernel, 17 % of all wave cycles stalled on LDS issue -- while 10 % fewer VALU instructions changed nothing.  The kernel
+//    is bound by LDS instruction throughput (a 4-byte read moves 75-128 B/clk, a 16-byte one 160-256).
+//  * here: half a wave = one row, lane = columns 4 q .. 4 q + 3, planes in natural column order.  A lane reads ONLY ITS OWN
+//    columns: one ds_read_b128 per plane row it touches (one ds_read_b64 of the compacted half-density planes), whatever the
+//    number of taps in that row; the taps of the neighbour columns (reach <= 4 = one quad) come from the neighbour lanes'
+//    registers through DPP wavefront shifts (v_*_dpp wave_shr:1 / wave_shl:1, folded into the consuming instruction by
+//    hipcc: +2 cycles, no extra instruction).  47 16-byte + 27 8-byte reads per lane and step = 19 reads per pixel.
+//  * the two halves of a wave take rows r and r + 4 of the 8-row block (same CFA phase, so the R/B column parity stays a
+//    compile-time constant of the wave's code variant); a shift that crosses lane 31 | 32 brings a value of the other row --
+//    into the outermost halo columns only, which hold garbage by construction (they read beyond the window in rs as well).
+//  * 256-thread workgroups (4 waves x 2 rows), the same 47 KB of planes: three workgroups per CU, 168 VGPRs per lane.
+#pragma once
+
+namespace rq {
+
+using namespace rs;  // plane geometry (CFA_B ... COL_B, *_L, *_W), LAG_*, RB, TWS, HALO, PAD, fdiv2, lmask, keep, SLOW / FASTM / INNER, slot16, Pair
+
+constexpr int NT = 256, HALO = rs::HALO;  // (declared here: rcd.hip's tile kernel has constants of the same names)
+
+// row offsets (floats, relative to the lane bases bF / bH) of plane row dr as seen by a step at `lag`
+template <int BASE, int LIVE, int LAGW> constexpr int rowF(int lag, int dr) { return BASE + (LIVE + LAGW - lag + dr) * 128; }
+template <int BASE, int LIVE, int LAGW> constexpr int rowH(int lag, int dr) { return BASE + (LIVE + LAGW - lag + dr) * 64; }
+
+constexpr int SLIDE_PT = (SLIDE_SLOTS + NT - 1) / NT;  // float4 slide slots per thread: 5 (the last round for 128 threads)
+static_assert(SLIDE_SLOTS % 64 == 0, "slide rounds end on a wave boundary");
+
+struct F4 { float v[4]; };
+struct F2 { float v[2]; };
+// 16-byte / 8-byte LDS accesses as native vector types (a struct of two floats is split into scalar loads before the back end
+// sees its alignment, and comes back as a bank-conflicting ds_read2_b32)
+typedef float vec4f __attribute__((ext_vector_type(4)));
+typedef float vec2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F4 ldF(const float* p) {
+  const vec4f t = *reinterpret_cast<const vec4f*>(__builtin_assume_aligned(p, 16));
+  return F4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ F2 ldH(const float* p) {
+  const vec2f t = *reinterpret_cast<const vec2f*>(__builtin_assume_aligned(p, 8));
+  return F2{{t.x, t.y}};
+}
+__device__ __forceinline__ void stF(float* p, float a, float b, float c, float d) { *reinterpret_cast<vec4f*>(__builtin_assume_aligned(p, 16)) = vec4f{a, b, c, d}; }
+__device__ __forceinline__ void stH(float* p, float a, float b) { *reinterpret_cast<vec2f*>(__builtin_assume_aligned(p, 8)) = vec2f{a, b}; }
+
+// the value the lane below / above holds in the same register (0 at the wave's ends)
+__device__ __forceinline__ float from_lo(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, true)); }  // wave_shr:1
+__device__ __forceinline__ float from_hi(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true)); }  // wave_shl:1
+
+// column idx of a plane row relative to the lane's first column, -4 <= idx <= 7 (idx is a constant after unrolling)
+__device__ __forceinline__ float tapF(const F4& r, int idx) {
+  return idx < 0 ? from_lo(r.v[(idx + 4) & 3]) : (idx > 3 ? from_hi(r.v[(idx - 4) & 3]) : r.v[idx & 3]);
+}
+// entry idx of a compacted row relative to the lane's first entry, -2 <= idx <= 3
+__device__ __forceinline__ float tapH(const F2& r, int idx) {
+  return idx < 0 ? from_lo(r.v[(idx + 2) & 1]) : (idx > 1 ? from_hi(r.v[(idx - 2) & 1]) : r.v[idx & 1]);
+}
+
+// per-thread view of a step: lane bases, frame position of the lane's first column, the frame rows of its site in each step
+struct Lane {
+  float* bF;   // lds + row_in_block * 128 + 4 q
+  float* bH;   // lds + row_in_block * 64 + 2 q
+  int gxq;     // frame x of column 0 of the quad
+  int w, h;
+};
+// border rule of site column ci for this lane, as a lane mask (non-INNER variants only: border blocks)
+__device__ __forceinline__ lmask colrow(bool row_ok, int gx, int lo, int hi) { return __builtin_amdgcn_ballot_w64(row_ok && gx >= lo && gx <= hi); }
+
+// ---- steps 2.1 (lag 1), 1.1 and 4.1 (lag 3)
+template <int MODE, int PE, typename TI>
+__device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const TI* __restrict__ in) {
+  // ---- step 2.1: lpf at the two R/B sites of the quad
+  {
+    constexpr int L = LAG_21, p = PE ^ (L & 1);
+    F4 c[3];
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++) c[dr + 1] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+    float o[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int ci = p + 2 * k;
+      auto a = [&](int dr, int dc) { return tapF(c[dr + 1], ci + dc); };
+      const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
+      if constexpr (MODE == INNER) o[k] = v;
+      else { const int gy = gyb - L; o[k] = keep(colrow(gy >= 2 && gy <= t.h - 2, t.gxq + ci, 2, t.w - 2), v); }
+    }
+    stH(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, 0), o[0], o[1]);
+  }
+  // ---- steps 1.1 (v_diff / h_diff at all four columns) and 4.1 (p/q_diff at the odd columns): the same seven CFA rows
+  {
+    constexpr int L = LAG_11;
+    static_assert(LAG_41 == LAG_11, "steps 1.1 and 4.1 share their CFA rows");
+    F4 c[7];
+#pragma unroll
+    for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+    const int gy = gyb - L;
+    float vd[4], hd[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ci++) {
+      auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+      vd[ci] = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
+      hd[ci] = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
+      if constexpr (MODE != INNER) {
+        const lmask ok = colrow(gy >= 3 && gy <= t.h - 4, t.gxq + ci, 3, t.w - 4);
+        vd[ci] = keep(ok, vd[ci]);
+        hd[ci] = keep(ok, hd[ci]);
+      }
+    }
+    stF(t.bF + rowF<VD_B, VD_L, VD_W>(L, 0), vd[0], vd[1], vd[2], vd[3]);
+    stF(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0), hd[0], hd[1], hd[2], hd[3]);
+    float pv[2], qv[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int ci = 1 + 2 * k;
+      auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+      pv[k] = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
+      qv[k] = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
+      if constexpr (MODE != INNER) {
+        // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
+        // rcd.hip); outside the frame: 0
+        const int gx = t.gxq + ci;
+        const bool inside = gy >= 0 && gy < t.h && gx >= 0 && gx < t.w, ranged = gy >= 3 && gy <= t.h - 4 && gx >= 3 && gx <= t.w - 4;
+        if (__builtin_amdgcn_ballot_w64(inside && !ranged) != 0) {
+          if (inside && !ranged) { pv[k] = stale_diff(in, gy, gx, t.w, t.h, true); qv[k] = stale_diff(in, gy, gx, t.w, t.h, false); }
+        }
+        const lmask m = __builtin_amdgcn_ballot_w64(inside);
+        pv[k] = keep(m, pv[k]);
+        qv[k] = keep(m, qv[k]);
+      }
+    }
+    stH(t.bH + rowH<P_B, P_L, P_W>(L, 0), pv[0], pv[1]);
+    stH(t.bH + rowH<Q_B, Q_L, Q_W>(L, 0), qv[0], qv[1]);
+  }
+}
+
+// ---- steps 1.2 (VH_dir at all four columns) and 4.2 (PQ_dir at the R/B sites), lag 4
+template <int MODE, int PE>
+__device__ __forceinline__ void q_step_1_2_4_2(const Lane& t, int gyb) {
+  constexpr int L = LAG_12;
+  static_assert(LAG_42 == LAG_12, "steps 1.2 and 4.2 run at the same lag");
+  const int gy = gyb - L;
+  {
+    F4 vdr[3];
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++) vdr[dr + 1] = ldF(t.bF + rowF<VD_B, VD_L, VD_W>(L, dr));
+    const F4 hdr = ldF(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0));
+    float vh[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ci++) {
+      const float eps = 1e-10f;
+      const float V_Stat = fmaxf(eps, vdr[0].v[ci] + vdr[1].v[ci] + vdr[2].v[ci]);
+      const float H_Stat = fmaxf(eps, tapF(hdr, ci - 1) + tapF(hdr, ci) + tapF(hdr, ci + 1));
+      vh[ci] = div_pos<MODE != SLOW>(V_Stat, V_Stat + H_Stat);
+      if constexpr (MODE != INNER) vh[ci] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + ci, 2, t.w - 3), vh[ci]);
+    }
+    stF(t.bF + rowF<VH_B, VH_L, VH_W>(L, 0), vh[0], vh[1], vh[2], vh[3]);
+  }
+  {
+    // p/q slot of odd column 2 j + 1 = entry j; the slots of (col - 1) | 1 on the neighbour rows: j - 1 + p (rcd.cu:166-182)
+    constexpr int p = PE ^ (L & 1), jm = p - 1;
+    F2 pr[3], qr[3];
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++) {
+      pr[dr + 1] = ldH(t.bH + rowH<P_B, P_L, P_W>(L, dr));
+      qr[dr + 1] = ldH(t.bH + rowH<Q_B, Q_L, Q_W>(L, dr));
+    }
+    float pq[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const float eps = 1e-10f;
+      const float P_Stat = fmaxf(eps, tapH(pr[0], k + jm) + pr[1].v[k] + tapH(pr[2], k + jm + 1));
+      const float Q_Stat = fmaxf(eps, tapH(qr[0], k + jm + 1) + qr[1].v[k] + tapH(qr[2], k + jm));
+      // plain division wherever a stale slot (see step 4.1) can be near: it holds values of samples no range check has seen
+      pq[k] = div_pos<MODE == INNER>(P_Stat, P_Stat + Q_Stat);
+      if constexpr (MODE != INNER) pq[k] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + p + 2 * k, 2, t.w - 3), pq[k]);
+    }
+    stH(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, 0), pq[0], pq[1]);
+  }
+}
+
+// ---- step 3.1 (lag 5): green at the two R/B sites
+template <int MODE, int PE>
+__device__ __forceinline__ void q_step_3_1(const Lane& t, int gyb) {
+  constexpr int L = LAG_31, p = PE ^ (L & 1);
+  F4 c[9], vhr[3];
+  F2 lpr[5];
+#pragma unroll
+  for (int dr = -4; dr <= 4; dr++) c[dr + 4] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++) vhr[dr + 1] = ldF(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
+#pragma unroll
+  for (int dr = -2; dr <= 2; dr++) lpr[dr + 2] = ldH(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, dr));
+  float g[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int ci = p + 2 * k;
+    auto a = [&](int dr, int dc) { return tapF(c[dr + 4], ci + dc); };
+    auto vh = [&](int dr, int dc) { return tapF(vhr[dr + 1], ci + dc); };
+    auto lp = [&](int dr, int sh) { return tapH(lpr[dr + 2], k + sh); };
+    const float eps = 1e-5f;
+    const float VH_c = vh(0, 0);
+    const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
+    const float VH_Disc = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+    const float cfai = a(0, 0);
+    const float N_Grad = eps + fabsf(a(-1, 0) - a(1, 0)) + fabsf(cfai - a(-2, 0)) + fabsf(a(-1, 0) - a(-3, 0)) + fabsf(a(-2, 0) - a(-4, 0));
+    const float S_Grad = eps + fabsf(a(1, 0) - a(-1, 0)) + fabsf(cfai - a(2, 0)) + fabsf(a(1, 0) - a(3, 0)) + fabsf(a(2, 0) - a(4, 0));
+    const float W_Grad = eps + fabsf(a(0, -1) - a(0, 1)) + fabsf(cfai - a(0, -2)) + fabsf(a(0, -1) - a(0, -3)) + fabsf(a(0, -2) - a(0, -4));
+    const float E_Grad = eps + fabsf(a(0, 1) - a(0, -1)) + fabsf(cfai - a(0, 2)) + fabsf(a(0, 1) - a(0, 3)) + fabsf(a(0, 2) - a(0, 4));
+    const float lpfi = lp(0, 0);
+    const float N_Est = div_pos<MODE != SLOW>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
+    const float S_Est = div_pos<MODE != SLOW>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
+    const float W_Est = div_pos<MODE != SLOW>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
+    const float E_Est = div_pos<MODE != SLOW>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
+    const float V_Est = div_pos<MODE != SLOW>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
+    const float H_Est = div_pos<MODE != SLOW>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
+    g[k] = mixf(V_Est, H_Est, VH_Disc);
+    if constexpr (MODE != INNER) { const int gy = gyb - L; g[k] = keep(colrow(gy >= 4 && gy <= t.h - 5, t.gxq + ci, 4, t.w - 5), g[k]); }
+  }
+  stH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, 0), g[0], g[1]);
+}
+
+// ---- step 5.1 (lag 7): the opposite colour at the two R/B sites.  `rel`: the lanes whose numerators count in the wave's
+// fast-division test (the outermost quads compute on garbage, which nothing that is stored ever reads).
+template <int MODE, int PE>
+__device__ __forceinline__ void q_step_5_1(const Lane& t, int gyb, lmask rel) {
+  constexpr int L = LAG_51, p = PE ^ (L & 1);
+  F4 c[7];  // rows -3, -1, 1, 3 are read
+  F2 pqr[3], gr[5];
+#pragma unroll
+  for (int dr = -3; dr <= 3; dr += 2) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++) pqr[dr + 1] = ldH(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, dr));
+#pragma unroll
+  for (int dr = -2; dr <= 2; dr++) gr[dr + 2] = ldH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
+  float num[4], den[4], g0v[2], disc[2];
+  lmask ok[2];
+  float mn = 1.0f;  // smallest numerator magnitude over the sites that count
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int ci = p + 2 * k;
+    auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+    auto pq = [&](int dr, int sh) { return tapH(pqr[dr + 1], k + sh); };
+    // green of R/B site (row + dr, col + dc): rows of the same parity keep the site's entry shifted by dc / 2, the other rows
+    // hold their R/B sites on the other column parity: entry k + (p + dc - (1 - p)) / 2
+    auto G = [&](int dr, int dc) { return tapH(gr[dr + 2], k + ((dr & 1) ? fdiv2(2 * p + dc - 1) : dc / 2)); };
+    constexpr int s = p - 1;  // entry of slot (col - 1) / 2 on the neighbour rows (rcd.cu:199-207)
+    const float eps = 1e-5f;
+    const float PQ_c = pq(0, 0);
+    const float PQ_n = 0.25f * (pq(-1, s) + pq(-1, s + 1) + pq(1, s) + pq(1, s + 1));
+    disc[k] = (fabsf(0.5f - PQ_c) < fabsf(0.5f - PQ_n)) ? PQ_n : PQ_c;
+    const float g0 = G(0, 0);
+    g0v[k] = g0;
+    const float NW_Grad = eps + fabsf(a(-1, -1) - a(1, 1)) + fabsf(a(-1, -1) - a(-3, -3)) + fabsf(g0 - G(-2, -2));
+    const float NE_Grad = eps + fabsf(a(-1, 1) - a(1, -1)) + fabsf(a(-1, 1) - a(-3, 3)) + fabsf(g0 - G(-2, 2));
+    const float SW_Grad = eps + fabsf(a(-1, 1) - a(1, -1)) + fabsf(a(1, -1) - a(3, -3)) + fabsf(g0 - G(2, -2));
+    const float SE_Grad = eps + fabsf(a(-1, -1) - a(1, 1)) + fabsf(a(1, 1) - a(3, 3)) + fabsf(g0 - G(2, 2));
+    const float NW_Est = a(-1, -1) - G(-1, -1);
+    const float NE_Est = a(-1, 1) - G(-1, 1);
+    const float SW_Est = a(1, -1) - G(1, -1);
+    const float SE_Est = a(1, 1) - G(1, 1);
+    num[2 * k] = NW_Grad * SE_Est + SE_Grad * NW_Est;
+    num[2 * k + 1] = NE_Grad * SW_Est + SW_Grad * NE_Est;
+    den[2 * k] = NW_Grad + SE_Grad;
+    den[2 * k + 1] = NE_Grad + SW_Grad;
+    if constexpr (MODE == INNER) ok[k] = rel;
+    else { const int gy = gyb - L; ok[k] = colrow(gy >= 4 && gy <= t.h - 4, t.gxq + ci, 4, t.w - 4); }
+    if constexpr (MODE != SLOW) {
+      float r;  // min(|num|) of the site where it counts, 1 elsewhere
+      const float m2 = fminf(fabsf(num[2 * k]), fabsf(num[2 * k + 1]));
+      const lmask cnt = MODE == INNER ? rel : (ok[k] & rel);
+      asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(r) : "v"(m2), "s"(cnt));
+      mn = fminf(mn, r);
+    }
+  }
+  float est[4];  // P_Est, Q_Est of the two sites
+  div_signed_min<MODE != SLOW>(num, den, est, mn);
+  float o[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    o[k] = g0v[k] + mixf(est[2 * k], est[2 * k + 1], disc[k]);
+    if constexpr (MODE != INNER) o[k] = keep(ok[k], o[k]);
+  }
+  stH(t.bH + rowH<COL_B, COL_L, COL_W>(L, 0), o[0], o[1]);
+}
+
+// ---- step 5.2 (lag 10) at the two green sites of the quad + its four finished pixels.  sto[ci]: column ci of this lane is
+// stored; stm: the lanes that store anything (their numerators count in the fast-division test).
+template <int MODE, int PE, typename T>
+__device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* __restrict__ dst, const bool (&sto)[4], lmask stm) {
+  constexpr int L = LAG_52, p = PE ^ (L & 1), pg = 1 - p;  // R/B sites on parity p, the green sites on pg
+  F4 c[7], vhr[3];
+  F2 gr[3], cr[7];  // colour rows -3, -1, 0, 1, 3 are read
+#pragma unroll
+  for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++) {
+    vhr[dr + 1] = ldF(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
+    gr[dr + 1] = ldH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
+  }
+#pragma unroll
+  for (int dr = -3; dr <= 3; dr++)
+    if (dr != -2 && dr != 2) cr[dr + 3] = ldH(t.bH + rowH<COL_B, COL_L, COL_W>(L, dr));
+  float num[8], den[8], gsite[2], disc[2];
+  float mn = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int ci = pg + 2 * k;
+    auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+    auto vh = [&](int dr, int dc) { return tapF(vhr[dr + 1], ci + dc); };
+    auto grn = [&](int dr, int sh) { return tapH(gr[dr + 1], k + sh); };
+    auto col = [&](int dr, int sh) { return tapH(cr[dr + 3], k + sh); };
+    const float eps = 1e-5f;
+    const float VH_c = vh(0, 0);
+    const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
+    disc[k] = (fabsf(0.5f - VH_c) < fabsf(0.5f - VH_n)) ? VH_n : VH_c;
+    const float g = a(0, 0);
+    gsite[k] = g;
+    const float N1 = eps + fabsf(g - a(-2, 0));
+    const float S1 = eps + fabsf(g - a(2, 0));
+    const float W1 = eps + fabsf(g - a(0, -2));
+    const float E1 = eps + fabsf(g - a(0, 2));
+    // green at the four R/B neighbours: above / below the site's own entry (those rows hold their R/B sites on this column's
+    // parity), left / right the entries of columns col -+ 1 of this row
+    const float gN = grn(-1, 0), gS = grn(1, 0), gW = grn(0, -p), gE = grn(0, 1 - p);
+    // colour of this row's R/B sites (`own`): native left / right, from step 5.1 above / below; the other colour the other way round
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+      float cN, cS, cW, cE, cN3, cS3, cW3, cE3;
+      if (cc == 0) {
+        cW = a(0, -1); cE = a(0, 1); cW3 = a(0, -3); cE3 = a(0, 3);
+        cN = col(-1, 0); cS = col(1, 0); cN3 = col(-3, 0); cS3 = col(3, 0);
+      } else {
+        cW = col(0, -p); cE = col(0, 1 - p); cW3 = col(0, -p - 1); cE3 = col(0, 2 - p);
+        cN = a(-1, 0); cS = a(1, 0); cN3 = a(-3, 0); cS3 = a(3, 0);
+      }
+      const float SNabs = fabsf(cN - cS);
+      const float EWabs = fabsf(cW - cE);
+      const float N_Grad = N1 + SNabs + fabsf(cN - cN3);
+      const float S_Grad = S1 + SNabs + fabsf(cS - cS3);
+      const float W_Grad = W1 + EWabs + fabsf(cW - cW3);
+      const float E_Grad = E1 + EWabs + fabsf(cE - cE3);
+      const float N_Est = cN - gN;
+      const float S_Est = cS - gS;
+      const float W_Est = cW - gW;
+      const float E_Est = cE - gE;
+      num[4 * k + 2 * cc] = N_Grad * S_Est + S_Grad * N_Est;
+      den[4 * k + 2 * cc] = N_Grad + S_Grad;
+      num[4 * k + 2 * cc + 1] = E_Grad * W_Est + W_Grad * E_Est;
+      den[4 * k + 2 * cc + 1] = E_Grad + W_Grad;
+    }
+    if constexpr (MODE != SLOW) {
+      float r;
+      const float m4 = fminf(fminf(fabsf(num[4 * k]), fabsf(num[4 * k + 1])), fminf(fabsf(num[4 * k + 2]), fabsf(num[4 * k + 3])));
+      asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(r) : "v"(m4), "s"(stm));
+      mn = fminf(mn, r);
+    }
+  }
+  float est[8];
+  div_signed_min<MODE != SLOW>(num, den, est, mn);
+  // pixels of the two column pairs (2 k, 2 k + 1): the R/B pixel (native, green from step 3.1, other colour from step 5.1) and
+  // the green pixel
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float g = gsite[k];
+    const float own = fmaxf(g + mixf(est[4 * k], est[4 * k + 1], disc[k]), 0.0f), oth = fmaxf(g + mixf(est[4 * k + 2], est[4 * k + 3], disc[k]), 0.0f);
+    const float native = fmaxf(c[3].v[p + 2 * k], 0.0f), green = fmaxf(gr[1].v[k], 0.0f), other = fmaxf(cr[3].v[k], 0.0f);
+    const float gg = fmaxf(g, 0.0f);
+    T* d = dst + 6 * k;
+    const bool st0 = sto[2 * k], st1 = sto[2 * k + 1];
+    // {R, B} of the green pixel and of the R/B pixel; red_row is wave-uniform: a branch, not six selects
+    auto store = [&](float gr_, float gb_, float rr_, float rb_) {
+      // column 2 k first: the R/B pixel when the R/B sites of this row sit on even columns
+      const float f0 = p == 0 ? rr_ : gr_, f1 = p == 0 ? green : gg, f2 = p == 0 ? rb_ : gb_;
+      const float s0 = p == 0 ? gr_ : rr_, s1 = p == 0 ? gg : green, s2 = p == 0 ? gb_ : rb_;
+      if (st0 && st1) {
+        if constexpr (sizeof(T) == 4) {
+          struct alignas(8) px6 { float a, b, c, d, e, f; };
+          *reinterpret_cast<px6*>(d) = px6{f0, f1, f2, s0, s1, s2};
+        } else {
+          struct alignas(4) pair6 { __half2 a, b, c; };
+          *reinterpret_cast<pair6*>(d) = pair6{__floats2half2_rn(f0, f1), __floats2half2_rn(f2, s0), __floats2half2_rn(s1, s2)};
+        }
+      } else if (st0) {  // the frame's last stored column is even (w - 8) ...
+        ::st(d, 0, f0); ::st(d, 1, f1); ::st(d, 2, f2);
+      } else if (st1) {  // ... its first one odd (7)
+        ::st(d, 3, s0); ::st(d, 4, s1); ::st(d, 5, s2);
+      }
+    };
+    if (red_row) store(own, oth, native, other);
+    else store(oth, own, other, native);
+  }
+}
+
+// Workgroup = one segment of one strip (grid: nstrips * nsegs) as in rs::rcd_stream; 256 threads: wave wv, half hf of the wave
+// -> row wv + 4 hf of the step's 8-row block, lane q of the half -> window columns 4 q .. 4 q + 3.
+template <typename TI, typename T>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void rcd_quad(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern,
+                                                                                           int nstrips, int seg_rows, int nbx, int nby) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane >> 5, q = lane & 31;
+  const int rr = wv + 4 * hf;  // row of this thread in a step's block
+  for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
+    ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
+    __syncthreads();
+  }
+  const int strip = (int)blockIdx.x % nstrips, seg = (int)blockIdx.x / nstrips;
+  const int xs = min(strip * TWS, w - TWS), ys = min(seg * seg_rows, h - seg_rows);
+  const int gx0 = xs - HALO, gy0 = ys - HALO;  // frame position of window column 0 / row 0; both even
+  const int nsteps = (seg_rows + 2 * HALO + RB - 1) / RB;
+  Lane t;
+  t.bF = lds + rr * 128 + 4 * q;
+  t.bH = lds + rr * 64 + 2 * q;
+  t.gxq = gx0 + 4 * q;
+  t.w = w; t.h = h;
+  uint32_t* verdict = reinterpret_cast<uint32_t*>(lds + LDS_FLOATS);
+
+  // R/B column parity of this wave's rows in the even-lag steps (rows wv and wv + 4: the same CFA phase)
+  const int rowpar0 = cfa_color(0, 0, pattern) & 1, rowpar1 = cfa_color(1, 0, pattern) & 1;
+  const int pe = ((gy0 + wv) & 1) ? rowpar1 : rowpar0;
+  const bool red_row = cfa_color(gy0 + wv, pe, pattern) == 0;  // colour of the R/B sites in this wave's output rows (lag 10: even)
+
+  // per column of the quad: inside the strip's own columns and the frame's stored range [7, w - 7) (a bit per column, in a
+  // VGPR: as lane masks they would cost four SGPR pairs for the whole kernel); the lanes that store anything; and the lanes
+  // with a site whose step-5.1 colour a stored pixel can read (3 columns beyond the own range)
+  int own7 = 0;
+#pragma unroll
+  for (int ci = 0; ci < 4; ci++) {
+    const int wc = 4 * q + ci, gx = t.gxq + ci;
+    own7 |= (wc >= HALO && wc < HALO + TWS && gx >= 7 && gx < w - 7) ? (1 << ci) : 0;
+  }
+  asm volatile("" : "+v"(own7));
+  const lmask own_lanes = __builtin_amdgcn_ballot_w64(own7 != 0);
+  const lmask rel51 = __builtin_amdgcn_ballot_w64(4 * q + 3 >= HALO - 4 && 4 * q < HALO + TWS + 4);
+  const bool quad_in = t.gxq >= 0 && t.gxq < w;  // the frame cuts the window at even columns: a column pair is in or out as a whole
+  const bool pair1_in = t.gxq + 2 >= 0 && t.gxq + 2 < w;
+  const bool inner_cols = gx0 >= 4 && gx0 + 127 <= w - 5;
+
+  int sd[SLIDE_PT], sdist[SLIDE_PT];
+#pragma unroll
+  for (int k = 0; k < SLIDE_PT; k++) slide_slot(tid + k * NT, sd[k], sdist[k]);
+  const bool last_round = tid + (SLIDE_PT - 1) * NT < SLIDE_SLOTS;  // whole waves
+
+  // samples of window row 8 b + rr, columns 4 q .. 4 q + 3 (two pairs); outside the frame: 0
+  Pair<TI> sa, sb;
+  bool in_a = false, in_b = false;
+  auto prefetch = [&](int b) {
+    const int gy = gy0 + RB * b + rr;
+    const bool row_in = gy >= 0 && gy < h;
+    in_a = row_in && quad_in;
+    in_b = row_in && pair1_in;
+    if (in_a) sa.fetch(in + (size_t)gy * w + t.gxq);
+    if (in_b) sb.fetch(in + (size_t)gy * w + t.gxq + 2);
+  };
+  prefetch(0);
+  bool ok1 = false, ok2 = false;  // range verdicts of the two previous blocks
+
+  for (int b = 0; b < nsteps; b++) {
+    // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
+    if (b > 0) {
+      // (named registers, not an array: across the fence of the barrier an array would be kept in scratch memory)
+      static_assert(SLIDE_PT == 5, "five slide slots per thread");
+      const float4 s0 = *slot16(lds + sd[0] + sdist[0]), s1 = *slot16(lds + sd[1] + sdist[1]), s2 = *slot16(lds + sd[2] + sdist[2]),
+                   s3 = *slot16(lds + sd[3] + sdist[3]);
+      float4 s4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (last_round) s4 = *slot16(lds + sd[4] + sdist[4]);
+      wg_barrier();
+      *slot16(lds + sd[0]) = s0;
+      *slot16(lds + sd[1]) = s1;
+      *slot16(lds + sd[2]) = s2;
+      *slot16(lds + sd[3]) = s3;
+      if (last_round) *slot16(lds + sd[4]) = s4;
+    }
+    // ---- the new CFA rows (max(0, in)), their range verdict, and the next block's samples on their way
+    {
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      if (in_a) { const float2 v = sa.get(); a0 = fmaxf(0.0f, v.x); a1 = fmaxf(0.0f, v.y); }
+      if (in_b) { const float2 v = sb.get(); a2 = fmaxf(0.0f, v.x); a3 = fmaxf(0.0f, v.y); }
+      stF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(0, 0), a0, a1, a2, a3);
+      Range rg;
+      rg.add(a0); rg.add(a1); rg.add(a2); rg.add(a3);
+      const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
+      if (lane == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      if (b + 1 < nsteps) prefetch(b + 1);
+    }
+    wg_barrier();
+    uint32_t all = 1u;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) all &= verdict[(b & 3) * 8 + k];
+    const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
+    const bool fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
+    ok2 = ok1; ok1 = ok0;
+    // the rows of every step of this block (lags 1 .. 10 behind rows gy0 + 8 b .. + 7) inside every step's row range
+    const bool inner = inner_cols && gy0 + RB * b - LAG_52 >= 4 && gy0 + RB * b + RB - 1 - LAG_21 <= h - 5;
+
+    const int gyb = gy0 + RB * b + rr;  // frame row of this thread's lag-0 site
+    const int orow = RB * b - LAG_52 + rr, gyo = gy0 + orow;
+    const bool rout = orow >= HALO && orow < HALO + seg_rows && gyo >= 7 && gyo < h - 7;
+    bool st[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ci++) st[ci] = rout && ((own7 >> ci) & 1) != 0;
+    const lmask stm = __builtin_amdgcn_ballot_w64(rout) & own_lanes;
+    T* dst = out + ((size_t)gyo * w + t.gxq) * 3;
+
+#define RQ_STEP(MODEV, PEV)                                              \
+  do {                                                                   \
+    q_step_2_1_1_1_4_1<MODEV, PEV, TI>(t, gyb, in);                      \
+    wg_barrier();                                                        \
+    q_step_1_2_4_2<MODEV, PEV>(t, gyb);                                  \
+    wg_barrier();                                                        \
+    q_step_3_1<MODEV, PEV>(t, gyb);                                      \
+    wg_barrier();                                                        \
+    q_step_5_1<MODEV, PEV>(t, gyb, rel51);                               \
+    wg_barrier();                                                        \
+    q_step_5_2_out<MODEV, PEV, T>(t, red_row, dst, st, stm);             \
+  } while (0)
+    if (fast && inner) { if (pe) RQ_STEP(INNER, 1); else RQ_STEP(INNER, 0); }
+    else if (fast) { if (pe) RQ_STEP(FASTM, 1); else RQ_STEP(FASTM, 0); }
+    else { if (pe) RQ_STEP(SLOW, 1); else RQ_STEP(SLOW, 0); }
+#undef RQ_STEP
+  }
+}
+
+}  // namespace rq

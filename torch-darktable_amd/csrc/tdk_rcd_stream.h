@@ -112,9 +112,11 @@ struct Rows {  // of the current block, for this wave
 };
 __device__ __forceinline__ lmask rule(bool row_ok, lmask cols) { return row_ok ? cols : 0ull; }
 // v where the lane's bit of m is set, +0 elsewhere
+// (s_nop 1: two wait states between a VALU write of the mask -- a ballot straight from v_cmp -- and this read of it as a lane
+// mask, which hipcc cannot see inside the asm; scalar-made masks need none, and the rules only exist in border blocks)
 __device__ __forceinline__ float keep(lmask m, float v) {
   float r;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
   return r;
 }
 
