@@ -536,9 +536,10 @@ def test_laplacian_level_schedules(td, oracle, dev, scene, size):
     got = npy(td.Laplacian(dev, (w, h), td.LaplacianParams(6, *prm)).process(gpu(lum, dev)))
     ref = oracle.laplacian(lum, *prm)
     d = np.abs(got - ref)
-    # measured (profiles/r03/bounds_probe.json, and 0.98 % for test_laplacian's strongest curve): at most 2 binary16 ulps of
-    # the value, on at most 1 % of the pixels
-    assert np.isfinite(got).all() and (d <= 2.0 * half_ulp(np.maximum(np.abs(got), np.abs(ref)))).all() and (d > 0).mean() < 1.5e-2, (size, d.max(), (d > 0).mean())
+    # the curve is evaluated in the oracle's operation order (csrc/laplacian.hip): measured bit-identical on every schedule
+    # (profiles/r04/bounds_probe.json).  The clarity term goes through the hardware exp2 where the oracle calls libm, so a rare
+    # binary16 rounding flip stays allowed: at most 1 binary16 ulp of the value on at most 1e-4 of the pixels
+    assert np.isfinite(got).all() and (d <= 1.0 * half_ulp(np.maximum(np.abs(got), np.abs(ref)))).all() and (d > 0).mean() <= 1e-4, (size, d.max(), (d > 0).mean())
 
 
 @pytest.mark.parametrize('prm', [(0.2, 1.0, 1.0, 0.0), (0.2, 1.6, 0.7, 0.3), (0.35, 0.5, 1.5, -0.2)])
@@ -548,12 +549,14 @@ def test_laplacian(td, oracle, dev, scene, prm):
     ws = td.Laplacian(dev, (w, h), td.LaplacianParams(6, *prm))
     got = npy(ws.process(gpu(lum, dev)))
     ref = oracle.laplacian(lum, *prm)
-    # fp16 storage at every level: an fp32-math difference of 1 ulp can flip a half rounding (one binary16 ulp of the result,
-    # 4.9e-4 below 1.0); the curve is evaluated in a factored form with FMA contraction (csrc/laplacian.hip), so a fraction of
-    # a percent of the pixels see such a flip somewhere in their pyramid (two flips can stack: 2 ulps)
+    # fp16 storage at every level, fp32 math in the oracle's operation order: without the clarity term the result is the
+    # oracle's bit for bit; with it (hardware exp2 against libm expf) a rare binary16 rounding flip is allowed: 1 binary16 ulp
+    # of the value on at most 1e-4 of the pixels (measured: none, profiles/r04/bounds_probe.json)
     d = np.abs(got - ref)
-    # measured: <= 2 binary16 ulps of the value (4.9e-4 absolute) on 0.1 - 0.98 % of the pixels (profiles/r03/bounds_probe.json)
-    assert (d <= 2.0 * half_ulp(np.maximum(np.abs(got), np.abs(ref)))).all() and (d > 0).mean() < 1.5e-2, (d.max(), (d > 0).mean())
+    if prm[3] == 0.0:
+        assert np.array_equal(got, ref), (d.max(), (d > 0).mean())
+    else:
+        assert (d <= 1.0 * half_ulp(np.maximum(np.abs(got), np.abs(ref)))).all() and (d > 0).mean() <= 1e-4, (d.max(), (d > 0).mean())
     with pytest.raises(RuntimeError):
         td.Laplacian(dev, (w, h), td.LaplacianParams(num_gamma=4))
 

@@ -112,33 +112,51 @@ __device__ __forceinline__ float reduce25_half(const __half* __restrict__ fine, 
   return acc;
 }
 
-// laplacian.cu:266-290, written on the magnitude u = |x - g| (the curve is odd around g up to the shadows /
-// highlights factor):   outer = g + sgn (sigma + sh (u - sigma)),   inner = g + sgn sigma t (2 + t (sh - 1)),  t = u / 2 sigma
-// -- the reference's  g + s 2 (1 - t) t + t t (s + s sh)  with s = sgn sigma factored out (the reference is a
-// --use_fast_math build: contraction and reassociation are its compiler's choice as well; every result is rounded to
-// binary16 right after).  Per-launch constants are hoisted into CurveK; HAS_CLARITY = false skips the Gaussian term.
-#pragma clang fp contract(fast)
+// laplacian.cu:266-290 in the oracle's operation order (oracle/src/laplacian.c curve()), no FMA contraction, the quotient
+// c / (2 ssigma) correctly rounded: q = c rc, r = c - q d exactly (fma), q + r rc (Markstein) with rc = +-1 / (2 sigma) rounded
+// on the host -- exact for every finite c this kernel can see (|c| <= 2 sigma on this branch and >= 2^-26 or 0: x is a
+// binary16 value, g a multiple of 1/12) as long as sigma itself is ordinary (checked per launch: CurveK::plain_div otherwise).
+// Round 3 evaluated a factored form under contraction (12 instead of ~26 instructions): a fraction of a percent of the pixels
+// then saw a binary16 rounding flip somewhere in their pyramid.  With this form the whole filter is bit-identical to the oracle
+// on every size / parameter set of the tests and of profiles/bounds_probe.py (level-1 kernel 128 -> 169 us, level-0 assemble
+// 93 -> 103 us at 12 MP: profiles/r04/experiments/laplacian_faithful_curve.txt) -- parity first.  The clarity term keeps the
+// hardware exp2 (the reference is a --use_fast_math build); per-launch constants are hoisted into CurveK.
 struct CurveK {
   float sigma, two_sigma, inv_two_sigma, shadows, highlights, clarity, neg_inv_e;  // neg_inv_e = -log2(e) / (2 sigma^2 / 3)
+  bool plain_div;
 };
 __device__ __forceinline__ CurveK make_curve(float sigma, float shadows, float highlights, float clarity) {
   CurveK k;
   k.sigma = sigma; k.two_sigma = 2 * sigma; k.inv_two_sigma = 1.0f / (2.0f * sigma);
   k.shadows = shadows; k.highlights = highlights; k.clarity = clarity;
   k.neg_inv_e = -1.44269504088896341f / (2.0f * sigma * sigma / 3.0f);
+  k.plain_div = !(sigma >= 0x1p-20f && sigma <= 0x1p20f);
   return k;
 }
 template <bool HAS_CLARITY> __device__ __forceinline__ float curve(float x, float g, const CurveK& k) {
-  const float c = x - g, u = fabsf(c);
-  const float sh = (c > 0.0f) ? k.shadows : k.highlights;
-  const float t = fminf(u * k.inv_two_sigma, 1.0f);
-  const float outer = k.sigma + sh * (u - k.sigma);
-  const float inner = k.sigma * t * (2.0f + t * (sh - 1.0f));
-  float val = g + copysignf((u > k.two_sigma) ? outer : inner, c);
+  const float c = x - g;
+  // c > 0 ? sigma : -sigma; at c == 0 either sign gives val = g (t = 0 annihilates both terms), so the sign bit of c serves
+  const float ssigma = copysignf(k.sigma, c);
+  const float shadhi = c > 0.0f ? k.shadows : k.highlights;
+  const float lin = g + ssigma + shadhi * (c - ssigma);  // linear part
+  // blend in via quadratic bezier
+  const float d = 2.0f * ssigma;
+  float q;
+  if (__builtin_expect(k.plain_div, 0)) {
+    q = c / d;
+  } else {
+    const float rc = copysignf(k.inv_two_sigma, c);
+    const float q0 = c * rc;
+    q = __builtin_fmaf(__builtin_fmaf(-q0, d, c), rc, q0);
+  }
+  const float t = fminf(fmaxf(q, 0.0f), 1.0f);
+  const float t2 = t * t;
+  const float mt = 1.0f - t;
+  const float bez = g + d * mt * t + t2 * (ssigma + ssigma * shadhi);  // ssigma * 2.0f == d
+  float val = (fabsf(c) > k.two_sigma) ? lin : bez;
   if constexpr (HAS_CLARITY) val += k.clarity * c * __builtin_amdgcn_exp2f(c * c * k.neg_inv_e);  // hardware exp2 (fast-math build)
   return val;
 }
-#pragma clang fp contract(off)
 __device__ __forceinline__ float gamma_centre(int k) { return ((float)k + 0.5f) / (float)NG; }
 
 // ---------------------------------------------------------------- level 0 -> level 1, all seven pyramids
