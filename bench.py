@@ -215,7 +215,7 @@ def stages(workload: str, s: int):
             'denoise': (3 * s + 3 * s, ['tdk_compute_luminance', 'tdk_wiener(tiles)', 'tdk_wiener(finish+modify)']),
             'local_contrast': (3 * s + 3 * s, ['tdk_bilateral(tiles)', 'tdk_bilateral(tables)', 'tdk_bilateral(slice+modify)', 'tdk_bilateral(splat)',
                                                 'tdk_bilateral(blur_xy)', 'tdk_bilateral(blur_z)']),
-            'tonemap': (3 * s + 3, ['tdk_image_metrics_accumulate', 'tdk_image_metrics_finish', 'tdk_tonemap']),
+            'tonemap': (3 * s + 3, ['tdk_image_metrics', 'tdk_image_metrics_accumulate', 'tdk_image_metrics_finish', 'tdk_tonemap']),
         }
     if workload == 'rcd':
         return {'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(border)'])}
@@ -242,7 +242,8 @@ def launch_bytes_per_px(kernel: str, s: int) -> float | None:
         'tdk_wiener(finish)': 4 + 1 * s,
         'tdk_bilateral(tiles)': 4 + 3 * s + 3 * s,             # fp32 lightness in, RGB in, RGB out
         'tdk_tonemap': 3 * s + 3,
-        'tdk_image_metrics_accumulate': 3 * s / 64.0,          # stride-8 sample grid
+        'tdk_image_metrics': 3 * s / 64.0,                     # stride-8 sample grid (one launch: sums + finish by the last workgroup)
+        'tdk_image_metrics_accumulate': 3 * s / 64.0,
         'tdk_image_metrics_finish': 0.0,
         'tdk_rcd(border)': 0.0,                                # the 7-px ring: its bytes are in tdk_rcd's boundary count
         'tdk_bilateral(tables)': 0.0,                          # axis tables, a few hundred KB, once per workspace

@@ -156,8 +156,9 @@ int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stre
 /* The same statistics with a wide accumulator: TDK_METRICS_ACC_FLOATS device floats (TDK_METRICS_SLOTS rows of 8, 16-byte
  * aligned, ZERO before the first use).  _accumulate_rows adds one image's sums -- one partial per workgroup, spread over
  * the rows, so the grid is not capped by same-address atomics; _finish_reset sums the rows in a fixed order, writes
- * metrics[5] normalised by max(valid, 1) and zeroes the accumulator again.  Stream-ordered launches, no in-kernel
- * "last workgroup" hand-off.  tdk_image_metrics = the two calls for one image. */
+ * metrics[5] normalised by max(valid, 1) and zeroes the accumulator again (stream-ordered launches).
+ * tdk_image_metrics = both for ONE image (or the last image of a list) in ONE launch: the workgroup that draws the last
+ * ticket (word 6 of row 0, agent-scope counter) sums the rows and resets them; results identical to the two calls. */
 #define TDK_METRICS_SLOTS 1024
 #define TDK_METRICS_ACC_FLOATS (TDK_METRICS_SLOTS * 8)
 int tdk_image_metrics_accumulate_rows(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows,

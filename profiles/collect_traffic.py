@@ -42,7 +42,7 @@ KERNELS = {
     'rcd_border': ('tdk_rcd(border)', False),
     'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
     'bilateral_axis_tables_kernel': ('tdk_bilateral(tables)', False),
-    'metrics_kernel': ('tdk_image_metrics_accumulate', False),
+    'metrics_kernel': ('tdk_image_metrics', False),
     'metrics_finish_reset_kernel': ('tdk_image_metrics_finish', False),
     'splat_gather_kernel': ('tdk_bilateral(splat)', False),
     'blur_xy_kernel': ('tdk_bilateral(blur_xy)', False),

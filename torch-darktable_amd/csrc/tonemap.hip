@@ -78,13 +78,57 @@ __global__ void metrics_init_kernel(float* acc) {
   if (threadIdx.x < 8) acc[threadIdx.x] = 0.0f;
 }
 
+// Sum of the TDK_METRICS_SLOTS accumulator rows in a fixed order by one 256-thread workgroup, normalised (color_adaption.cu:161-165)
+// into metrics[0..4]; the rows (and the ticket word in row 0) are zeroed for the next image.  AGENT_LOADS: the rows were
+// written by other workgroups of the SAME launch (float atomics, which execute at the memory side and leave nothing in L2): they
+// are read with agent-scope loads that bypass this CU's vector L1.
+template <bool AGENT_LOADS>
+__device__ __forceinline__ void metrics_finish_rows(float* __restrict__ acc, float* __restrict__ metrics, float (*part)[6]) {
+  static_assert(TDK_METRICS_SLOTS == 4 * 256, "four rows per thread");
+  float v[4][6];  // all loads in flight before the first use
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int r = threadIdx.x + 256 * j;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[j][k] = AGENT_LOADS ? __hip_atomic_load(&acc[r * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[r * 8 + k];
+  }
+  float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) s[k] += v[j][k];
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float* row = acc + (threadIdx.x + 256 * j) * 8;
+    reinterpret_cast<float4*>(row)[0] = z;
+    reinterpret_cast<float4*>(row)[1] = z;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    const float v = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+    const float cnt = (part[0][5] + part[1][5]) + (part[2][5] + part[3][5]);
+    metrics[k] = v * (1.0f / fmaxf(cnt, 1.0f));  // color_adaption.cu:161-165
+  }
+}
+
 // ROWS: the workgroup's partial sums go to row (blockIdx.x mod TDK_METRICS_SLOTS) of a wide accumulator instead of
 // acc[0..5] -- no same-address contention, so the grid can be as wide as the image needs (the single-row form is kept
 // for the three-call API, whose accumulator is 8 floats, and caps its grid at one workgroup per CU).
+// finish_to (ROWS only, may be null): the workgroup that draws the last ticket also sums the rows, writes the five metrics
+// there and zeroes the accumulator -- compute_image_metrics of ONE image as one launch instead of two.  The hand-off follows
+// cdna_hip_programming.md Guideline 16 (counter form): every adding lane's atomics have completed (s_waitcnt vmcnt(0)), the
+// workgroup's barrier, then one lane draws the ticket with an agent-scope fetch_add; the last arriver reads the rows with
+// agent-scope loads (metrics_finish_rows<true>).  The ticket is word 6 of row 0, which the sums never touch.
 template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
-                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc) {
+                                                      float min_gray, const float* __restrict__ bounds, float* __restrict__ acc, float* __restrict__ finish_to) {
   __shared__ float part[4][6];
+  __shared__ int last_block;
   const int64_t n = (int64_t)sw * sh;
   const float b0 = bounds[0];
   const float range = bounds[1] - b0 + 1e-6f;
@@ -114,6 +158,23 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
     const float mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     atomicAdd(&acc[(ROWS ? (blockIdx.x & (TDK_METRICS_SLOTS - 1)) * 8 : 0) + threadIdx.x], mine);
   }
+  if constexpr (ROWS) {
+    if (finish_to) {  // kernel argument: uniform
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's six adds have reached memory
+      __syncthreads();
+      // (no release fence: the sums are memory-side atomics, nothing of them sits in this XCD's L2; no acquire: the last
+      // workgroup reads the rows with agent-scope loads)
+      if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(acc + 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = t == gridDim.x - 1u;
+      }
+      __syncthreads();
+      if (last_block) {  // workgroup-uniform (LDS word)
+        __syncthreads();  // `part` is reused
+        metrics_finish_rows<true>(acc, finish_to, part);  // also zeroes row 0's ticket word
+      }
+    }
+  }
 }
 
 // color_adaption.cu:161-165
@@ -124,31 +185,11 @@ __global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __re
   }
 }
 
-// finish + self-clean for sums accumulated in TDK_METRICS_SLOTS rows of 8 floats (tdk_bilateral_rgb_fused spreads its
-// workgroups over the rows; tdk_image_metrics_accumulate uses row 0): one workgroup, stream-ordered after the adds;
-// rows are summed in a fixed order.
+// finish + self-clean for sums accumulated in TDK_METRICS_SLOTS rows of 8 floats by earlier launches
+// (tdk_image_metrics_accumulate_rows, one per image): one workgroup, stream-ordered after the adds; rows are summed in a fixed order.
 __global__ __launch_bounds__(256) void metrics_finish_reset_kernel(float* __restrict__ acc, float* __restrict__ metrics) {
   __shared__ float part[4][6];
-  float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  for (int r = threadIdx.x; r < TDK_METRICS_SLOTS; r += 256) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) s[k] += acc[r * 8 + k];
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    reinterpret_cast<float4*>(acc + r * 8)[0] = z;
-    reinterpret_cast<float4*>(acc + r * 8)[1] = z;
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float v = wave_sum(s[k]);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    const int k = threadIdx.x;
-    const float v = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
-    const float cnt = (part[0][5] + part[1][5]) + (part[2][5] + part[3][5]);
-    metrics[k] = v * (1.0f / fmaxf(cnt, 1.0f));  // color_adaption.cu:161-165
-  }
+  metrics_finish_rows<false>(acc, metrics, part);
 }
 
 // ------------------------------------------------------------------ tonemaps
@@ -321,28 +362,33 @@ TDK_EXPORT int tdk_image_metrics_accumulate(const void* rgb, int width, int heig
   const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
   const int grid = reduce_grid((int64_t)sw * sh);
   TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", (metrics_kernel<T, false>), dim3(grid), dim3(256), 0, tdk_stream(stream),
-                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc));
+                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc, static_cast<float*>(nullptr)));
+  return TDK_OK;
+}
+
+static int metrics_rows(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows, float* finish_to,
+                        int dtype, tdk_stream_t stream, const char* what) {
+  TDK_REQUIRE(rgb && bounds && acc_rows, "%s: null pointer", what);
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "%s: invalid size/stride", what);
+  TDK_REQUIRE(tdk_aligned(acc_rows, 16), "%s: acc must be 16-byte aligned", what);
+  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
+  // every sample is three scattered loads: latency-bound, so spread it over many workgroups (2 samples per thread)
+  int64_t grid = tdk_div_up64((int64_t)sw * sh, 512);
+  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH(finish_to ? "tdk_image_metrics" : "tdk_image_metrics_accumulate", (metrics_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0,
+                                          tdk_stream(stream), reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc_rows, finish_to));
   return TDK_OK;
 }
 
 TDK_EXPORT int tdk_image_metrics_accumulate_rows(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds,
                                                  float* acc_rows, int dtype, tdk_stream_t stream) {
-  TDK_REQUIRE(rgb && bounds && acc_rows, "tdk_image_metrics_accumulate_rows: null pointer");
-  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_metrics_accumulate_rows: invalid size/stride");
-  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
-  // every sample is three scattered loads: latency-bound, so spread it over many workgroups (2 samples per thread)
-  int64_t grid = tdk_div_up64((int64_t)sw * sh, 512);
-  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
-  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_metrics_accumulate", (metrics_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, tdk_stream(stream),
-                                                  reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, min_gray, bounds, acc_rows));
-  return TDK_OK;
+  return metrics_rows(rgb, width, height, stride, min_gray, bounds, acc_rows, nullptr, dtype, stream, "tdk_image_metrics_accumulate_rows");
 }
 
 TDK_EXPORT int tdk_image_metrics(const void* rgb, int width, int height, int stride, float min_gray, const float* bounds, float* acc_rows,
                                  float* metrics, int dtype, tdk_stream_t stream) {
   TDK_REQUIRE(metrics, "tdk_image_metrics: null pointer");
-  const int rc = tdk_image_metrics_accumulate_rows(rgb, width, height, stride, min_gray, bounds, acc_rows, dtype, stream);
-  return rc != TDK_OK ? rc : tdk_image_metrics_finish_reset(acc_rows, metrics, stream);
+  return metrics_rows(rgb, width, height, stride, min_gray, bounds, acc_rows, metrics, dtype, stream, "tdk_image_metrics");
 }
 
 TDK_EXPORT int tdk_image_metrics_finish(const float* acc, float* metrics, tdk_stream_t stream) {

@@ -529,11 +529,13 @@ def compute_image_metrics(images: Sequence[torch.Tensor], stride: int = 8, min_g
 
 
 class MetricsAccumulator:
-  """compute_image_metrics in two halves: `add(image)` accumulates one image's sample-grid sums
-  (tdk_image_metrics_accumulate_rows: a wide accumulator, so the launch is not capped by same-address atomics),
-  `finish()` normalises by the valid-sample count (color_adaption.cu:161-165), returns the 5 metrics on the device
-  and leaves the accumulator zero for the next frame.  Stream order is the only synchronisation.
-  compute_image_metrics(images) == [acc.add(i) for i in images]; acc.finish()."""
+  """compute_image_metrics in two halves: `add(image)` takes one image's sample-grid sums (a wide accumulator, so the launch
+  is not capped by same-address atomics), `finish()` normalises by the valid-sample count (color_adaption.cu:161-165), returns
+  the 5 metrics on the device and leaves the accumulator zero for the next frame.  Stream order is the only synchronisation.
+  compute_image_metrics(images) == [acc.add(i) for i in images]; acc.finish().
+  The kernel of the LAST image added also does the finish (tdk_image_metrics: one launch, the workgroup that draws the last
+  ticket sums the rows), so the usual one image per frame costs one launch; for that the launch of an added image is issued
+  when the next image arrives or at finish() -- on the stream that is current THEN."""
 
   def __init__(self, device, stride: int = 8, min_gray: float = 1e-4, bounds: torch.Tensor | None = None):
     device = torch.device(device)
@@ -541,26 +543,41 @@ class MetricsAccumulator:
     self.stride, self.min_gray = int(stride), float(min_gray)
     self.bounds = bounds.to(device=device, dtype=torch.float32).contiguous() if bounds is not None else _unit_bounds(device)
     self.acc = torch.zeros(8192, dtype=torch.float32, device=device)  # TDK_METRICS_ACC_FLOATS: 1024 rows of 8
+    self._pending: torch.Tensor | None = None
 
-  def add(self, image: torch.Tensor) -> None:
-    _check_rgb(image, allow_half=True)
-    _require(image.device == self.acc.device, f'image is on {image.device}, the accumulator on {self.acc.device}')
-    x = image.contiguous()
+  def _launch(self, x: torch.Tensor, metrics: torch.Tensor | None) -> None:
     with torch.cuda.device(x.device):
       try:
-        check(lib.tdk_image_metrics_accumulate_rows(_ptr(x), x.size(1), x.size(0), self.stride, self.min_gray, _ptr(self.bounds), _ptr(self.acc),
-                                                    _dtype_tag(x), _stream()))
+        if metrics is None:
+          check(lib.tdk_image_metrics_accumulate_rows(_ptr(x), x.size(1), x.size(0), self.stride, self.min_gray, _ptr(self.bounds), _ptr(self.acc),
+                                                      _dtype_tag(x), _stream()))
+        else:
+          check(lib.tdk_image_metrics(_ptr(x), x.size(1), x.size(0), self.stride, self.min_gray, _ptr(self.bounds), _ptr(self.acc), _ptr(metrics),
+                                      _dtype_tag(x), _stream()))
       except Exception:
         self.reset()  # never leave half-accumulated sums behind
         raise
 
+  def add(self, image: torch.Tensor) -> None:
+    _check_rgb(image, allow_half=True)
+    _require(image.device == self.acc.device, f'image is on {image.device}, the accumulator on {self.acc.device}')
+    if self._pending is not None:
+      pending, self._pending = self._pending, None
+      self._launch(pending, None)
+    self._pending = image.contiguous()
+
   def finish(self) -> torch.Tensor:
     metrics = torch.empty(5, dtype=torch.float32, device=self.acc.device)
-    with torch.cuda.device(self.acc.device):
-      check(lib.tdk_image_metrics_finish_reset(_ptr(self.acc), _ptr(metrics), _stream()))
+    if self._pending is not None:
+      pending, self._pending = self._pending, None
+      self._launch(pending, metrics)
+    else:  # nothing added since the last finish: the metrics of an empty list (all zero: the valid count is clamped to 1)
+      with torch.cuda.device(self.acc.device):
+        check(lib.tdk_image_metrics_finish_reset(_ptr(self.acc), _ptr(metrics), _stream()))
     return metrics
 
   def reset(self) -> None:
+    self._pending = None
     self.acc.zero_()
 
 
