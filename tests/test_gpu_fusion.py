@@ -106,3 +106,105 @@ def test_batch_on_two_streams_equals_back_to_back(td, dev):
             assert torch.equal(outs[i], ref[i]), f'frame {i} differs between the two-stream and the one-stream run'
     one = FrameStreams(dev, make, streams=1).run(inputs)
     assert all(torch.equal(a, b) for a, b in zip(one, ref))
+
+
+def test_metrics_one_launch_equals_two_launches(td, dev):
+    """tdk_image_metrics (sums + finish by the workgroup that draws the last ticket, ONE launch) gives the bits of
+    tdk_image_metrics_accumulate_rows + tdk_image_metrics_finish_reset (two stream-ordered launches), leaves the accumulator
+    (ticket included) zero, and keeps doing so frame after frame on the same accumulator; a list of images = accumulate the
+    first ones, fuse the last."""
+    import ctypes as C
+
+    from torch_darktable._native import lib
+    from torch_darktable.synthetic import synthetic_rgb
+
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bounds = torch.tensor([0.0, 1.0], device=dev)
+    acc1 = torch.zeros(8192, device=dev)
+    acc2 = torch.zeros(8192, device=dev)
+    imgs = [synthetic_rgb(h, w, seed=s, device=dev).to(dt) for (h, w, s, dt) in
+            [(3072, 4096, 5, torch.float16), (250, 334, 6, torch.float32), (64, 64, 7, torch.float32), (1500, 2100, 8, torch.float16)]]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    tag = lambda t: 1 if t.dtype == torch.float16 else 0
+    for rep in range(3):
+        for x in imgs:
+            m1, m2 = torch.empty(5, device=dev), torch.empty(5, device=dev)
+            assert lib.tdk_image_metrics(p(x), x.size(1), x.size(0), 8, 1e-4, p(bounds), p(acc1), p(m1), tag(x), stream) == 0
+            assert lib.tdk_image_metrics_accumulate_rows(p(x), x.size(1), x.size(0), 8, 1e-4, p(bounds), p(acc2), tag(x), stream) == 0
+            assert lib.tdk_image_metrics_finish_reset(p(acc2), p(m2), stream) == 0
+            assert torch.equal(m1, m2), (rep, tuple(x.shape), m1, m2)
+            assert not acc1.any() and not acc2.any()  # rows and ticket back to zero
+    # a list: the first images accumulate, the last launch finishes
+    acc = td.tonemap.MetricsAccumulator(dev, stride=8)
+    for x in imgs[1:]:
+        acc.add(x)
+    got = acc.finish()
+    assert torch.equal(got, td.compute_image_metrics(imgs[1:], stride=8))
+    mlist = torch.empty(5, device=dev)
+    for x in imgs[1:]:
+        assert lib.tdk_image_metrics_accumulate_rows(p(x), x.size(1), x.size(0), 8, 1e-4, p(bounds), p(acc2), tag(x), stream) == 0
+    assert lib.tdk_image_metrics_finish_reset(p(acc2), p(mlist), stream) == 0
+    assert torch.equal(got, mlist)
+    # an accumulator nobody added to: the metrics of an empty list
+    assert torch.equal(acc.finish(), torch.zeros(5, device=dev))
+
+
+def test_bilateral_prepared_workspace_and_flags(td, dev):
+    """The C ABI of the bilateral tile kernel: tdk_bilateral_prepare once + TDK_BILATERAL_PREPARED on every call == the plain
+    entry points (which build the axis tables themselves) == the four-kernel path (TDK_BILATERAL_GENERAL_PATH), for the plane
+    and the RGB layout sharing ONE prepared workspace, across different `detail` values; unknown flags are refused."""
+    import ctypes as C
+
+    from torch_darktable._native import lib
+
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (w, h, ss, sr) in [(334, 250, 2.0, 0.2), (1000, 96, 3.3, 0.1), (128, 64, 1.0, 0.25)]:
+        lum = torch.rand(h, w, generator=g, device=dev)
+        rgb = torch.rand(h, w, 3, generator=g, device=dev)
+        nbytes = max(lib.tdk_bilateral_workspace_bytes(w, h, ss, sr), lib.tdk_bilateral_rgb_workspace_bytes(w, h, ss, sr))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws.fill_(0xFF)  # garbage: nothing may depend on what the workspace held
+        assert lib.tdk_bilateral_prepare(p(ws), w, h, ss, sr, stream) == 0
+        for detail in (0.4, -0.3):
+            outs = []
+            for flags, wsp in ((1, ws), (0, ws2), (2, ws2)):
+                o = torch.empty_like(lum)
+                assert lib.tdk_bilateral_ex(p(lum), p(o), p(wsp), w, h, ss, sr, detail, 0, flags, stream) == 0
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (w, h, ss, sr, detail)
+            o_plain = torch.empty_like(lum)
+            assert lib.tdk_bilateral(p(lum), p(o_plain), p(ws2), w, h, ss, sr, detail, 0, stream) == 0
+            assert torch.equal(o_plain, outs[0])
+            routs = []
+            for flags, wsp in ((1, ws), (0, ws2), (2, ws2)):
+                o = torch.empty_like(rgb)
+                assert lib.tdk_bilateral_rgb_ex(p(rgb), p(None), p(o), p(wsp), w, h, ss, sr, detail, 0, 1e-6, 0, flags, stream) == 0
+                routs.append(o)
+            assert torch.equal(routs[0], routs[1]) and torch.equal(routs[0], routs[2]), (w, h, ss, sr, detail)
+        o = torch.empty_like(lum)
+        assert lib.tdk_bilateral_ex(p(lum), p(o), p(ws), w, h, ss, sr, 0.4, 0, 8, stream) != 0
+        assert b'unknown flags' in lib.tdk_last_error()
+
+
+def test_verification_paths_are_thread_local(td, dev):
+    """verification_paths() selects the second kernel path of RCD / Bilateral for the calling thread only (the library takes
+    the path per call: tdk_rcd_ex / tdk_bilateral_ex flags); another thread keeps the default meanwhile."""
+    import threading
+
+    from torch_darktable import torch_darktable_extension as ext
+
+    seen = {}
+
+    def other():
+        seen['other'] = (getattr(ext._verify, 'rcd', 0), getattr(ext._verify, 'bil', 0))
+
+    with ext.verification_paths(rcd_tiles=True, bilateral_general=True):
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        seen['mine'] = (ext._verify.rcd, ext._verify.bil)
+    assert seen['other'] == (0, 0) and seen['mine'] == (ext.TDK_RCD_TILE_KERNEL, ext.TDK_BILATERAL_GENERAL_PATH)
+    assert (ext._verify.rcd, ext._verify.bil) == (0, 0)

@@ -264,7 +264,11 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void tonemap_vec4(const T* __restrict__ in, uint32_t* __restrict__ out, int64_t ngroups,
                                                      const float* __restrict__ metrics, float gamma, float intensity, float light_adapt,
                                                      float vibrance) {
-  const TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
+  TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
+  // The per-image constants are wave-uniform, so hipcc keeps them in SGPRs -- and a VALU instruction with an SGPR source
+  // issues at half rate on gfx950 (4.4 instead of 2.4 cycles, tests/hip_unit/valu_issue_bench.hip); they are used ~20 times
+  // per pixel.  Through an empty asm they become VGPR values (one v_mov each, once per thread).
+  asm volatile("" : "+v"(k.key), "+v"(k.inv_exposure), "+v"(k.m0), "+v"(k.m1), "+v"(k.m2), "+v"(k.inv_gamma), "+v"(k.light_adapt), "+v"(k.aces_scale));
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
     float v[12];
     rgb4_io<T>::load(in, g, v);
