@@ -14,7 +14,7 @@ One step = one pass of the hot path over one batch of device-resident synthetic 
   rcd (configs[1]): one 4096x3072 fp32 frame through RCD.process.
   ppg_wiener50 (configs[4]): 4 x 8192x6144 RGGB per GPU, fp16 storage, PPG.process -> Wiener.process C=3 (K=32, ov=4,
       sigma=0.05 as reference scripts/run_benchmark.py:96; the reference has no wavelet denoiser).
-The frames of a batch are independent; they are issued round-robin on --streams HIP streams (default 2), each with
+The frames of a batch are independent; they are issued round-robin on --streams HIP streams (default 3), each with
 its own op workspaces, so one frame's kernel tails overlap the next frame's kernels.
 
 Multi-GPU (BASELINE.json configs[3]): one process per GPU.  Frames are independent, so every rank
@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument('--workload', choices=['isp', 'rcd', 'ppg_wiener50'], default='isp')
     ap.add_argument('--storage', choices=['f16', 'f32'], default=None, help='image storage type (default: f32 for rcd, f16 otherwise)')
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 8 for isp, 1 for rcd, 4 for ppg_wiener50)')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--height', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle run (and with it the parity check)')
@@ -447,7 +447,8 @@ def main(argv=None):
     w, h = (args.width or (W50 if args.workload == 'ppg_wiener50' else W12)), (args.height or (H50 if args.workload == 'ppg_wiener50' else H12))
     # The frames of a batch are independent: they are issued round-robin on `nstreams` HIP streams, each with its own
     # op workspaces, so that the tail of one frame's kernels (partially filled last rounds, 1-workgroup finish kernels)
-    # overlaps the next frame's -- measured +13 % at 2-3 streams (profiles/streams_exp.py).
+    # overlaps the next frames' -- measured +13 % at 2 streams (profiles/streams_exp.py, round 2), +1.5 % more at 3 with round 4's
+    # kernels (profiles/r04/experiments/streams_sweep.txt); 4 streams lose 3 %.
     nstreams = max(1, min(args.streams, frames))
     from torch_darktable.sharding import FrameStreams
 

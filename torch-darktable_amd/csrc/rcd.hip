@@ -754,10 +754,16 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
 #endif
 #ifdef TDK_EXPERIMENTS
-      if (getenv("TDK_RCD_QUAD")) {
-        const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+      if (const char* e = getenv("TDK_RCD_QUAD")) {  // columns per lane of the register-tap variant: 2, else 4
+        if (atoi(e) == 2) {
+          const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<2, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+          if (rcq != TDK_OK) return rcq;
+          TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<2, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<2>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+          return TDK_OK;
+        }
+        const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<4, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
         if (rcq != TDK_OK) return rcq;
-        TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<TI, T>), dim3((unsigned)nwg), dim3(rq::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+        TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<4, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<4>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
         return TDK_OK;
       }
 #endif

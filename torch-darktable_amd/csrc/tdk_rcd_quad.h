@@ -24,43 +24,59 @@ namespace rq {
 
 using namespace rs;  // plane geometry (CFA_B ... COL_B, *_L, *_W), LAG_*, RB, TWS, HALO, PAD, fdiv2, lmask, keep, SLOW / FASTM / INNER, slot16, Pair
 
-constexpr int NT = 256, HALO = rs::HALO;  // (declared here: rcd.hip's tile kernel has constants of the same names)
+constexpr int HALO = rs::HALO;  // (declared here: rcd.hip's tile kernel has a constant of the same name)
+
+// CPL columns per lane: 4 (half a wave = one row, 256 threads, 12 waves per CU) or 2 (a wave = one row as in rs, 512 threads, 24
+// waves per CU; full planes read 8 bytes at a time, the half-density ones 4, taps up to two lanes away = two DPP shifts)
+template <int CPL> struct Geo {
+  static_assert(CPL == 2 || CPL == 4, "columns per lane");
+  static constexpr int LPR = 128 / CPL;  // lanes per row
+  static constexpr int NT = RB * LPR;    // threads
+  static constexpr int HPL = CPL / 2;    // entries of a half-density plane row per lane = sites of one kind per lane
+  static constexpr int WPE = 3 * NT / 256;  // waves per SIMD with three workgroups per CU
+  static constexpr int SLIDE_PT = (SLIDE_SLOTS + NT - 1) / NT;  // float4 slide slots per thread (the last round for 128 threads)
+  static_assert(SLIDE_SLOTS - (SLIDE_PT - 1) * NT == 128, "the last slide round is two whole waves");
+};
 
 // row offsets (floats, relative to the lane bases bF / bH) of plane row dr as seen by a step at `lag`
 template <int BASE, int LIVE, int LAGW> constexpr int rowF(int lag, int dr) { return BASE + (LIVE + LAGW - lag + dr) * 128; }
 template <int BASE, int LIVE, int LAGW> constexpr int rowH(int lag, int dr) { return BASE + (LIVE + LAGW - lag + dr) * 64; }
 
-constexpr int SLIDE_PT = (SLIDE_SLOTS + NT - 1) / NT;  // float4 slide slots per thread: 5 (the last round for 128 threads)
-static_assert(SLIDE_SLOTS % 64 == 0, "slide rounds end on a wave boundary");
-
-struct F4 { float v[4]; };
-struct F2 { float v[2]; };
+template <int N> struct Row { float v[N]; };
 // 16-byte / 8-byte LDS accesses as native vector types (a struct of two floats is split into scalar loads before the back end
 // sees its alignment, and comes back as a bank-conflicting ds_read2_b32)
 typedef float vec4f __attribute__((ext_vector_type(4)));
 typedef float vec2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ F4 ldF(const float* p) {
-  const vec4f t = *reinterpret_cast<const vec4f*>(__builtin_assume_aligned(p, 16));
-  return F4{{t.x, t.y, t.z, t.w}};
+template <int N> __device__ __forceinline__ Row<N> ldv(const float* p) {
+  if constexpr (N == 4) {
+    const vec4f t = *reinterpret_cast<const vec4f*>(__builtin_assume_aligned(p, 16));
+    return Row<4>{{t.x, t.y, t.z, t.w}};
+  } else if constexpr (N == 2) {
+    const vec2f t = *reinterpret_cast<const vec2f*>(__builtin_assume_aligned(p, 8));
+    return Row<2>{{t.x, t.y}};
+  } else {
+    return Row<1>{{*p}};
+  }
 }
-__device__ __forceinline__ F2 ldH(const float* p) {
-  const vec2f t = *reinterpret_cast<const vec2f*>(__builtin_assume_aligned(p, 8));
-  return F2{{t.x, t.y}};
+template <int N> __device__ __forceinline__ void stv(float* p, const float (&v)[N]) {
+  if constexpr (N == 4) *reinterpret_cast<vec4f*>(__builtin_assume_aligned(p, 16)) = vec4f{v[0], v[1], v[2], v[3]};
+  else if constexpr (N == 2) *reinterpret_cast<vec2f*>(__builtin_assume_aligned(p, 8)) = vec2f{v[0], v[1]};
+  else *p = v[0];
 }
-__device__ __forceinline__ void stF(float* p, float a, float b, float c, float d) { *reinterpret_cast<vec4f*>(__builtin_assume_aligned(p, 16)) = vec4f{a, b, c, d}; }
-__device__ __forceinline__ void stH(float* p, float a, float b) { *reinterpret_cast<vec2f*>(__builtin_assume_aligned(p, 8)) = vec2f{a, b}; }
 
 // the value the lane below / above holds in the same register (0 at the wave's ends)
 __device__ __forceinline__ float from_lo(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, true)); }  // wave_shr:1
 __device__ __forceinline__ float from_hi(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true)); }  // wave_shl:1
 
-// column idx of a plane row relative to the lane's first column, -4 <= idx <= 7 (idx is a constant after unrolling)
-__device__ __forceinline__ float tapF(const F4& r, int idx) {
-  return idx < 0 ? from_lo(r.v[(idx + 4) & 3]) : (idx > 3 ? from_hi(r.v[(idx - 4) & 3]) : r.v[idx & 3]);
-}
-// entry idx of a compacted row relative to the lane's first entry, -2 <= idx <= 3
-__device__ __forceinline__ float tapH(const F2& r, int idx) {
-  return idx < 0 ? from_lo(r.v[(idx + 2) & 1]) : (idx > 1 ? from_hi(r.v[(idx - 2) & 1]) : r.v[idx & 1]);
+// element idx of a plane row relative to the lane's first element, at most two lanes away (idx is a constant after unrolling)
+template <int N> __device__ __forceinline__ float tap(const Row<N>& r, int idx) {
+  const int s = idx >= 0 ? idx / N : -((N - 1 - idx) / N);  // lane distance: floor(idx / N)
+  float x = r.v[idx - s * N];
+  if (s <= -1) x = from_lo(x);
+  if (s <= -2) x = from_lo(x);
+  if (s >= 1) x = from_hi(x);
+  if (s >= 2) x = from_hi(x);
+  return x;
 }
 
 // per-thread view of a step: lane bases, frame position of the lane's first column, the frame rows of its site in each step
@@ -74,37 +90,37 @@ struct Lane {
 __device__ __forceinline__ lmask colrow(bool row_ok, int gx, int lo, int hi) { return __builtin_amdgcn_ballot_w64(row_ok && gx >= lo && gx <= hi); }
 
 // ---- steps 2.1 (lag 1), 1.1 and 4.1 (lag 3)
-template <int MODE, int PE, typename TI>
+template <int CPL, int MODE, int PE, typename TI>
 __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const TI* __restrict__ in) {
   // ---- step 2.1: lpf at the two R/B sites of the quad
   {
     constexpr int L = LAG_21, p = PE ^ (L & 1);
-    F4 c[3];
+    Row<CPL> c[3];
 #pragma unroll
-    for (int dr = -1; dr <= 1; dr++) c[dr + 1] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
-    float o[2];
+    for (int dr = -1; dr <= 1; dr++) c[dr + 1] = ldv<CPL>(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+    float o[CPL / 2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < CPL / 2; k++) {
       const int ci = p + 2 * k;
-      auto a = [&](int dr, int dc) { return tapF(c[dr + 1], ci + dc); };
+      auto a = [&](int dr, int dc) { return tap(c[dr + 1], ci + dc); };
       const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
       if constexpr (MODE == INNER) o[k] = v;
       else { const int gy = gyb - L; o[k] = keep(colrow(gy >= 2 && gy <= t.h - 2, t.gxq + ci, 2, t.w - 2), v); }
     }
-    stH(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, 0), o[0], o[1]);
+    stv(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, 0), o);
   }
   // ---- steps 1.1 (v_diff / h_diff at all four columns) and 4.1 (p/q_diff at the odd columns): the same seven CFA rows
   {
     constexpr int L = LAG_11;
     static_assert(LAG_41 == LAG_11, "steps 1.1 and 4.1 share their CFA rows");
-    F4 c[7];
+    Row<CPL> c[7];
 #pragma unroll
-    for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+    for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldv<CPL>(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
     const int gy = gyb - L;
-    float vd[4], hd[4];
+    float vd[CPL], hd[CPL];
 #pragma unroll
-    for (int ci = 0; ci < 4; ci++) {
-      auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+    for (int ci = 0; ci < CPL; ci++) {
+      auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
       vd[ci] = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
       hd[ci] = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
       if constexpr (MODE != INNER) {
@@ -113,13 +129,13 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
         hd[ci] = keep(ok, hd[ci]);
       }
     }
-    stF(t.bF + rowF<VD_B, VD_L, VD_W>(L, 0), vd[0], vd[1], vd[2], vd[3]);
-    stF(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0), hd[0], hd[1], hd[2], hd[3]);
-    float pv[2], qv[2];
+    stv(t.bF + rowF<VD_B, VD_L, VD_W>(L, 0), vd);
+    stv(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0), hd);
+    float pv[CPL / 2], qv[CPL / 2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < CPL / 2; k++) {
       const int ci = 1 + 2 * k;
-      auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
+      auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
       pv[k] = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
       qv[k] = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
       if constexpr (MODE != INNER) {
@@ -135,75 +151,75 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
         qv[k] = keep(m, qv[k]);
       }
     }
-    stH(t.bH + rowH<P_B, P_L, P_W>(L, 0), pv[0], pv[1]);
-    stH(t.bH + rowH<Q_B, Q_L, Q_W>(L, 0), qv[0], qv[1]);
+    stv(t.bH + rowH<P_B, P_L, P_W>(L, 0), pv);
+    stv(t.bH + rowH<Q_B, Q_L, Q_W>(L, 0), qv);
   }
 }
 
 // ---- steps 1.2 (VH_dir at all four columns) and 4.2 (PQ_dir at the R/B sites), lag 4
-template <int MODE, int PE>
+template <int CPL, int MODE, int PE>
 __device__ __forceinline__ void q_step_1_2_4_2(const Lane& t, int gyb) {
   constexpr int L = LAG_12;
   static_assert(LAG_42 == LAG_12, "steps 1.2 and 4.2 run at the same lag");
   const int gy = gyb - L;
   {
-    F4 vdr[3];
+    Row<CPL> vdr[3];
 #pragma unroll
-    for (int dr = -1; dr <= 1; dr++) vdr[dr + 1] = ldF(t.bF + rowF<VD_B, VD_L, VD_W>(L, dr));
-    const F4 hdr = ldF(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0));
-    float vh[4];
+    for (int dr = -1; dr <= 1; dr++) vdr[dr + 1] = ldv<CPL>(t.bF + rowF<VD_B, VD_L, VD_W>(L, dr));
+    const Row<CPL> hdr = ldv<CPL>(t.bF + rowF<HD_B, HD_L, HD_W>(L, 0));
+    float vh[CPL];
 #pragma unroll
-    for (int ci = 0; ci < 4; ci++) {
+    for (int ci = 0; ci < CPL; ci++) {
       const float eps = 1e-10f;
       const float V_Stat = fmaxf(eps, vdr[0].v[ci] + vdr[1].v[ci] + vdr[2].v[ci]);
-      const float H_Stat = fmaxf(eps, tapF(hdr, ci - 1) + tapF(hdr, ci) + tapF(hdr, ci + 1));
+      const float H_Stat = fmaxf(eps, tap(hdr, ci - 1) + tap(hdr, ci) + tap(hdr, ci + 1));
       vh[ci] = div_pos<MODE != SLOW>(V_Stat, V_Stat + H_Stat);
       if constexpr (MODE != INNER) vh[ci] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + ci, 2, t.w - 3), vh[ci]);
     }
-    stF(t.bF + rowF<VH_B, VH_L, VH_W>(L, 0), vh[0], vh[1], vh[2], vh[3]);
+    stv(t.bF + rowF<VH_B, VH_L, VH_W>(L, 0), vh);
   }
   {
     // p/q slot of odd column 2 j + 1 = entry j; the slots of (col - 1) | 1 on the neighbour rows: j - 1 + p (rcd.cu:166-182)
     constexpr int p = PE ^ (L & 1), jm = p - 1;
-    F2 pr[3], qr[3];
+    Row<CPL / 2> pr[3], qr[3];
 #pragma unroll
     for (int dr = -1; dr <= 1; dr++) {
-      pr[dr + 1] = ldH(t.bH + rowH<P_B, P_L, P_W>(L, dr));
-      qr[dr + 1] = ldH(t.bH + rowH<Q_B, Q_L, Q_W>(L, dr));
+      pr[dr + 1] = ldv<CPL / 2>(t.bH + rowH<P_B, P_L, P_W>(L, dr));
+      qr[dr + 1] = ldv<CPL / 2>(t.bH + rowH<Q_B, Q_L, Q_W>(L, dr));
     }
-    float pq[2];
+    float pq[CPL / 2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < CPL / 2; k++) {
       const float eps = 1e-10f;
-      const float P_Stat = fmaxf(eps, tapH(pr[0], k + jm) + pr[1].v[k] + tapH(pr[2], k + jm + 1));
-      const float Q_Stat = fmaxf(eps, tapH(qr[0], k + jm + 1) + qr[1].v[k] + tapH(qr[2], k + jm));
+      const float P_Stat = fmaxf(eps, tap(pr[0], k + jm) + pr[1].v[k] + tap(pr[2], k + jm + 1));
+      const float Q_Stat = fmaxf(eps, tap(qr[0], k + jm + 1) + qr[1].v[k] + tap(qr[2], k + jm));
       // plain division wherever a stale slot (see step 4.1) can be near: it holds values of samples no range check has seen
       pq[k] = div_pos<MODE == INNER>(P_Stat, P_Stat + Q_Stat);
       if constexpr (MODE != INNER) pq[k] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + p + 2 * k, 2, t.w - 3), pq[k]);
     }
-    stH(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, 0), pq[0], pq[1]);
+    stv(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, 0), pq);
   }
 }
 
 // ---- step 3.1 (lag 5): green at the two R/B sites
-template <int MODE, int PE>
+template <int CPL, int MODE, int PE>
 __device__ __forceinline__ void q_step_3_1(const Lane& t, int gyb) {
   constexpr int L = LAG_31, p = PE ^ (L & 1);
-  F4 c[9], vhr[3];
-  F2 lpr[5];
+  Row<CPL> c[9], vhr[3];
+  Row<CPL / 2> lpr[5];
 #pragma unroll
-  for (int dr = -4; dr <= 4; dr++) c[dr + 4] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+  for (int dr = -4; dr <= 4; dr++) c[dr + 4] = ldv<CPL>(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
 #pragma unroll
-  for (int dr = -1; dr <= 1; dr++) vhr[dr + 1] = ldF(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
+  for (int dr = -1; dr <= 1; dr++) vhr[dr + 1] = ldv<CPL>(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
 #pragma unroll
-  for (int dr = -2; dr <= 2; dr++) lpr[dr + 2] = ldH(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, dr));
-  float g[2];
+  for (int dr = -2; dr <= 2; dr++) lpr[dr + 2] = ldv<CPL / 2>(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, dr));
+  float g[CPL / 2];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < CPL / 2; k++) {
     const int ci = p + 2 * k;
-    auto a = [&](int dr, int dc) { return tapF(c[dr + 4], ci + dc); };
-    auto vh = [&](int dr, int dc) { return tapF(vhr[dr + 1], ci + dc); };
-    auto lp = [&](int dr, int sh) { return tapH(lpr[dr + 2], k + sh); };
+    auto a = [&](int dr, int dc) { return tap(c[dr + 4], ci + dc); };
+    auto vh = [&](int dr, int dc) { return tap(vhr[dr + 1], ci + dc); };
+    auto lp = [&](int dr, int sh) { return tap(lpr[dr + 2], k + sh); };
     const float eps = 1e-5f;
     const float VH_c = vh(0, 0);
     const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
@@ -223,33 +239,33 @@ __device__ __forceinline__ void q_step_3_1(const Lane& t, int gyb) {
     g[k] = mixf(V_Est, H_Est, VH_Disc);
     if constexpr (MODE != INNER) { const int gy = gyb - L; g[k] = keep(colrow(gy >= 4 && gy <= t.h - 5, t.gxq + ci, 4, t.w - 5), g[k]); }
   }
-  stH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, 0), g[0], g[1]);
+  stv(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, 0), g);
 }
 
 // ---- step 5.1 (lag 7): the opposite colour at the two R/B sites.  `rel`: the lanes whose numerators count in the wave's
 // fast-division test (the outermost quads compute on garbage, which nothing that is stored ever reads).
-template <int MODE, int PE>
+template <int CPL, int MODE, int PE>
 __device__ __forceinline__ void q_step_5_1(const Lane& t, int gyb, lmask rel) {
   constexpr int L = LAG_51, p = PE ^ (L & 1);
-  F4 c[7];  // rows -3, -1, 1, 3 are read
-  F2 pqr[3], gr[5];
+  Row<CPL> c[7];  // rows -3, -1, 1, 3 are read
+  Row<CPL / 2> pqr[3], gr[5];
 #pragma unroll
-  for (int dr = -3; dr <= 3; dr += 2) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+  for (int dr = -3; dr <= 3; dr += 2) c[dr + 3] = ldv<CPL>(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
 #pragma unroll
-  for (int dr = -1; dr <= 1; dr++) pqr[dr + 1] = ldH(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, dr));
+  for (int dr = -1; dr <= 1; dr++) pqr[dr + 1] = ldv<CPL / 2>(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, dr));
 #pragma unroll
-  for (int dr = -2; dr <= 2; dr++) gr[dr + 2] = ldH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
-  float num[4], den[4], g0v[2], disc[2];
-  lmask ok[2];
+  for (int dr = -2; dr <= 2; dr++) gr[dr + 2] = ldv<CPL / 2>(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
+  float num[CPL], den[CPL], g0v[CPL / 2], disc[CPL / 2];
+  lmask ok[CPL / 2];
   float mn = 1.0f;  // smallest numerator magnitude over the sites that count
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < CPL / 2; k++) {
     const int ci = p + 2 * k;
-    auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
-    auto pq = [&](int dr, int sh) { return tapH(pqr[dr + 1], k + sh); };
+    auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
+    auto pq = [&](int dr, int sh) { return tap(pqr[dr + 1], k + sh); };
     // green of R/B site (row + dr, col + dc): rows of the same parity keep the site's entry shifted by dc / 2, the other rows
     // hold their R/B sites on the other column parity: entry k + (p + dc - (1 - p)) / 2
-    auto G = [&](int dr, int dc) { return tapH(gr[dr + 2], k + ((dr & 1) ? fdiv2(2 * p + dc - 1) : dc / 2)); };
+    auto G = [&](int dr, int dc) { return tap(gr[dr + 2], k + ((dr & 1) ? fdiv2(2 * p + dc - 1) : dc / 2)); };
     constexpr int s = p - 1;  // entry of slot (col - 1) / 2 on the neighbour rows (rcd.cu:199-207)
     const float eps = 1e-5f;
     const float PQ_c = pq(0, 0);
@@ -279,43 +295,43 @@ __device__ __forceinline__ void q_step_5_1(const Lane& t, int gyb, lmask rel) {
       mn = fminf(mn, r);
     }
   }
-  float est[4];  // P_Est, Q_Est of the two sites
+  float est[CPL];  // P_Est, Q_Est of the sites
   div_signed_min<MODE != SLOW>(num, den, est, mn);
-  float o[2];
+  float o[CPL / 2];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < CPL / 2; k++) {
     o[k] = g0v[k] + mixf(est[2 * k], est[2 * k + 1], disc[k]);
     if constexpr (MODE != INNER) o[k] = keep(ok[k], o[k]);
   }
-  stH(t.bH + rowH<COL_B, COL_L, COL_W>(L, 0), o[0], o[1]);
+  stv(t.bH + rowH<COL_B, COL_L, COL_W>(L, 0), o);
 }
 
 // ---- step 5.2 (lag 10) at the two green sites of the quad + its four finished pixels.  sto[ci]: column ci of this lane is
 // stored; stm: the lanes that store anything (their numerators count in the fast-division test).
-template <int MODE, int PE, typename T>
-__device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* __restrict__ dst, const bool (&sto)[4], lmask stm) {
+template <int CPL, int MODE, int PE, typename T>
+__device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* __restrict__ dst, const bool (&sto)[CPL], lmask stm) {
   constexpr int L = LAG_52, p = PE ^ (L & 1), pg = 1 - p;  // R/B sites on parity p, the green sites on pg
-  F4 c[7], vhr[3];
-  F2 gr[3], cr[7];  // colour rows -3, -1, 0, 1, 3 are read
+  Row<CPL> c[7], vhr[3];
+  Row<CPL / 2> gr[3], cr[7];  // colour rows -3, -1, 0, 1, 3 are read
 #pragma unroll
-  for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
+  for (int dr = -3; dr <= 3; dr++) c[dr + 3] = ldv<CPL>(t.bF + rowF<CFA_B, CFA_L, CFA_W>(L, dr));
 #pragma unroll
   for (int dr = -1; dr <= 1; dr++) {
-    vhr[dr + 1] = ldF(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
-    gr[dr + 1] = ldH(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
+    vhr[dr + 1] = ldv<CPL>(t.bF + rowF<VH_B, VH_L, VH_W>(L, dr));
+    gr[dr + 1] = ldv<CPL / 2>(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, dr));
   }
 #pragma unroll
   for (int dr = -3; dr <= 3; dr++)
-    if (dr != -2 && dr != 2) cr[dr + 3] = ldH(t.bH + rowH<COL_B, COL_L, COL_W>(L, dr));
-  float num[8], den[8], gsite[2], disc[2];
+    if (dr != -2 && dr != 2) cr[dr + 3] = ldv<CPL / 2>(t.bH + rowH<COL_B, COL_L, COL_W>(L, dr));
+  float num[2 * CPL], den[2 * CPL], gsite[CPL / 2], disc[CPL / 2];
   float mn = 1.0f;
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < CPL / 2; k++) {
     const int ci = pg + 2 * k;
-    auto a = [&](int dr, int dc) { return tapF(c[dr + 3], ci + dc); };
-    auto vh = [&](int dr, int dc) { return tapF(vhr[dr + 1], ci + dc); };
-    auto grn = [&](int dr, int sh) { return tapH(gr[dr + 1], k + sh); };
-    auto col = [&](int dr, int sh) { return tapH(cr[dr + 3], k + sh); };
+    auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
+    auto vh = [&](int dr, int dc) { return tap(vhr[dr + 1], ci + dc); };
+    auto grn = [&](int dr, int sh) { return tap(gr[dr + 1], k + sh); };
+    auto col = [&](int dr, int sh) { return tap(cr[dr + 3], k + sh); };
     const float eps = 1e-5f;
     const float VH_c = vh(0, 0);
     const float VH_n = 0.25f * (vh(-1, -1) + vh(-1, 1) + vh(1, -1) + vh(1, 1));
@@ -362,12 +378,12 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
       mn = fminf(mn, r);
     }
   }
-  float est[8];
+  float est[2 * CPL];
   div_signed_min<MODE != SLOW>(num, den, est, mn);
   // pixels of the two column pairs (2 k, 2 k + 1): the R/B pixel (native, green from step 3.1, other colour from step 5.1) and
   // the green pixel
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < CPL / 2; k++) {
     const float g = gsite[k];
     const float own = fmaxf(g + mixf(est[4 * k], est[4 * k + 1], disc[k]), 0.0f), oth = fmaxf(g + mixf(est[4 * k + 2], est[4 * k + 3], disc[k]), 0.0f);
     const float native = fmaxf(c[3].v[p + 2 * k], 0.0f), green = fmaxf(gr[1].v[k], 0.0f), other = fmaxf(cr[3].v[k], 0.0f);
@@ -398,13 +414,16 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
   }
 }
 
-// Workgroup = one segment of one strip (grid: nstrips * nsegs) as in rs::rcd_stream; 256 threads: wave wv, half hf of the wave
-// -> row wv + 4 hf of the step's 8-row block, lane q of the half -> window columns 4 q .. 4 q + 3.
-template <typename TI, typename T>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void rcd_quad(const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern,
-                                                                                           int nstrips, int seg_rows, int nbx, int nby) {
+// Workgroup = one segment of one strip (grid: nstrips * nsegs) as in rs::rcd_stream.  CPL = 4: 256 threads, wave wv, half hf of
+// the wave -> row wv + 4 hf of the step's 8-row block, lane q of the half -> window columns 4 q .. 4 q + 3.  CPL = 2: 512 threads,
+// wave wv -> row wv, lane q -> columns 2 q, 2 q + 1.
+template <int CPL, typename TI, typename T>
+__global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Geo<CPL>::WPE, Geo<CPL>::WPE))) void rcd_quad(
+    const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nstrips, int seg_rows, int nbx, int nby) {
+  using G = Geo<CPL>;
+  constexpr int NT = G::NT, LPR = G::LPR, HPL = G::HPL, SLIDE_PT = G::SLIDE_PT;
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane >> 5, q = lane & 31;
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane / LPR, q = lane % LPR;
   const int rr = wv + 4 * hf;  // row of this thread in a step's block
   for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
     ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
@@ -415,9 +434,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const int gx0 = xs - HALO, gy0 = ys - HALO;  // frame position of window column 0 / row 0; both even
   const int nsteps = (seg_rows + 2 * HALO + RB - 1) / RB;
   Lane t;
-  t.bF = lds + rr * 128 + 4 * q;
-  t.bH = lds + rr * 64 + 2 * q;
-  t.gxq = gx0 + 4 * q;
+  t.bF = lds + rr * 128 + CPL * q;
+  t.bH = lds + rr * 64 + HPL * q;
+  t.gxq = gx0 + CPL * q;
   t.w = w; t.h = h;
   uint32_t* verdict = reinterpret_cast<uint32_t*>(lds + LDS_FLOATS);
 
@@ -426,20 +445,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const int pe = ((gy0 + wv) & 1) ? rowpar1 : rowpar0;
   const bool red_row = cfa_color(gy0 + wv, pe, pattern) == 0;  // colour of the R/B sites in this wave's output rows (lag 10: even)
 
-  // per column of the quad: inside the strip's own columns and the frame's stored range [7, w - 7) (a bit per column, in a
-  // VGPR: as lane masks they would cost four SGPR pairs for the whole kernel); the lanes that store anything; and the lanes
+  // per column of the lane: inside the strip's own columns and the frame's stored range [7, w - 7) (a bit per column, in a
+  // VGPR: as lane masks they would cost an SGPR pair each for the whole kernel); the lanes that store anything; and the lanes
   // with a site whose step-5.1 colour a stored pixel can read (3 columns beyond the own range)
   int own7 = 0;
 #pragma unroll
-  for (int ci = 0; ci < 4; ci++) {
-    const int wc = 4 * q + ci, gx = t.gxq + ci;
+  for (int ci = 0; ci < CPL; ci++) {
+    const int wc = CPL * q + ci, gx = t.gxq + ci;
     own7 |= (wc >= HALO && wc < HALO + TWS && gx >= 7 && gx < w - 7) ? (1 << ci) : 0;
   }
   asm volatile("" : "+v"(own7));
   const lmask own_lanes = __builtin_amdgcn_ballot_w64(own7 != 0);
-  const lmask rel51 = __builtin_amdgcn_ballot_w64(4 * q + 3 >= HALO - 4 && 4 * q < HALO + TWS + 4);
-  const bool quad_in = t.gxq >= 0 && t.gxq < w;  // the frame cuts the window at even columns: a column pair is in or out as a whole
-  const bool pair1_in = t.gxq + 2 >= 0 && t.gxq + 2 < w;
+  const lmask rel51 = __builtin_amdgcn_ballot_w64(CPL * q + CPL - 1 >= HALO - 4 && CPL * q < HALO + TWS + 4);
+  // the frame cuts the window at even columns: a column pair is in or out as a whole
+  bool pair_in[HPL];
+#pragma unroll
+  for (int k = 0; k < HPL; k++) pair_in[k] = t.gxq + 2 * k >= 0 && t.gxq + 2 * k < w;
   const bool inner_cols = gx0 >= 4 && gx0 + 127 <= w - 5;
 
   int sd[SLIDE_PT], sdist[SLIDE_PT];
@@ -447,16 +468,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   for (int k = 0; k < SLIDE_PT; k++) slide_slot(tid + k * NT, sd[k], sdist[k]);
   const bool last_round = tid + (SLIDE_PT - 1) * NT < SLIDE_SLOTS;  // whole waves
 
-  // samples of window row 8 b + rr, columns 4 q .. 4 q + 3 (two pairs); outside the frame: 0
-  Pair<TI> sa, sb;
-  bool in_a = false, in_b = false;
+  // samples of window row 8 b + rr, the lane's column pairs; outside the frame: 0
+  Pair<TI> smp[HPL];
+  bool smp_in[HPL];
+#pragma unroll
+  for (int k = 0; k < HPL; k++) smp_in[k] = false;
   auto prefetch = [&](int b) {
     const int gy = gy0 + RB * b + rr;
     const bool row_in = gy >= 0 && gy < h;
-    in_a = row_in && quad_in;
-    in_b = row_in && pair1_in;
-    if (in_a) sa.fetch(in + (size_t)gy * w + t.gxq);
-    if (in_b) sb.fetch(in + (size_t)gy * w + t.gxq + 2);
+#pragma unroll
+    for (int k = 0; k < HPL; k++) {
+      smp_in[k] = row_in && pair_in[k];
+      if (smp_in[k]) smp[k].fetch(in + (size_t)gy * w + t.gxq + 2 * k);
+    }
   };
   prefetch(0);
   bool ok1 = false, ok2 = false;  // range verdicts of the two previous blocks
@@ -465,26 +489,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
     if (b > 0) {
       // (named registers, not an array: across the fence of the barrier an array would be kept in scratch memory)
-      static_assert(SLIDE_PT == 5, "five slide slots per thread");
-      const float4 s0 = *slot16(lds + sd[0] + sdist[0]), s1 = *slot16(lds + sd[1] + sdist[1]), s2 = *slot16(lds + sd[2] + sdist[2]),
-                   s3 = *slot16(lds + sd[3] + sdist[3]);
-      float4 s4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (last_round) s4 = *slot16(lds + sd[4] + sdist[4]);
+      static_assert(SLIDE_PT == 5 || SLIDE_PT == 3, "slide slots per thread");
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      constexpr int LR = SLIDE_PT - 1;  // the round only two waves take
+      const float4 s0 = *slot16(lds + sd[0] + sdist[0]), s1 = *slot16(lds + sd[1] + sdist[1]);
+      float4 s2 = zero4, s3 = zero4, sl = zero4;
+      if constexpr (SLIDE_PT == 5) { s2 = *slot16(lds + sd[2] + sdist[2]); s3 = *slot16(lds + sd[3] + sdist[3]); }
+      if (last_round) sl = *slot16(lds + sd[LR] + sdist[LR]);
       wg_barrier();
       *slot16(lds + sd[0]) = s0;
       *slot16(lds + sd[1]) = s1;
-      *slot16(lds + sd[2]) = s2;
-      *slot16(lds + sd[3]) = s3;
-      if (last_round) *slot16(lds + sd[4]) = s4;
+      if constexpr (SLIDE_PT == 5) { *slot16(lds + sd[2]) = s2; *slot16(lds + sd[3]) = s3; }
+      if (last_round) *slot16(lds + sd[LR]) = sl;
     }
     // ---- the new CFA rows (max(0, in)), their range verdict, and the next block's samples on their way
     {
-      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-      if (in_a) { const float2 v = sa.get(); a0 = fmaxf(0.0f, v.x); a1 = fmaxf(0.0f, v.y); }
-      if (in_b) { const float2 v = sb.get(); a2 = fmaxf(0.0f, v.x); a3 = fmaxf(0.0f, v.y); }
-      stF(t.bF + rowF<CFA_B, CFA_L, CFA_W>(0, 0), a0, a1, a2, a3);
+      float a[CPL];
       Range rg;
-      rg.add(a0); rg.add(a1); rg.add(a2); rg.add(a3);
+#pragma unroll
+      for (int k = 0; k < HPL; k++) {
+        a[2 * k] = 0.0f; a[2 * k + 1] = 0.0f;
+        if (smp_in[k]) { const float2 v = smp[k].get(); a[2 * k] = fmaxf(0.0f, v.x); a[2 * k + 1] = fmaxf(0.0f, v.y); }
+        rg.add(a[2 * k]); rg.add(a[2 * k + 1]);
+      }
+      stv(t.bF + rowF<CFA_B, CFA_L, CFA_W>(0, 0), a);
       const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
       if (lane == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
       if (b + 1 < nsteps) prefetch(b + 1);
@@ -502,23 +530,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int gyb = gy0 + RB * b + rr;  // frame row of this thread's lag-0 site
     const int orow = RB * b - LAG_52 + rr, gyo = gy0 + orow;
     const bool rout = orow >= HALO && orow < HALO + seg_rows && gyo >= 7 && gyo < h - 7;
-    bool st[4];
+    bool st[CPL];
 #pragma unroll
-    for (int ci = 0; ci < 4; ci++) st[ci] = rout && ((own7 >> ci) & 1) != 0;
+    for (int ci = 0; ci < CPL; ci++) st[ci] = rout && ((own7 >> ci) & 1) != 0;
     const lmask stm = __builtin_amdgcn_ballot_w64(rout) & own_lanes;
     T* dst = out + ((size_t)gyo * w + t.gxq) * 3;
 
 #define RQ_STEP(MODEV, PEV)                                              \
   do {                                                                   \
-    q_step_2_1_1_1_4_1<MODEV, PEV, TI>(t, gyb, in);                      \
+    q_step_2_1_1_1_4_1<CPL, MODEV, PEV, TI>(t, gyb, in);                 \
     wg_barrier();                                                        \
-    q_step_1_2_4_2<MODEV, PEV>(t, gyb);                                  \
+    q_step_1_2_4_2<CPL, MODEV, PEV>(t, gyb);                             \
     wg_barrier();                                                        \
-    q_step_3_1<MODEV, PEV>(t, gyb);                                      \
+    q_step_3_1<CPL, MODEV, PEV>(t, gyb);                                 \
     wg_barrier();                                                        \
-    q_step_5_1<MODEV, PEV>(t, gyb, rel51);                               \
+    q_step_5_1<CPL, MODEV, PEV>(t, gyb, rel51);                          \
     wg_barrier();                                                        \
-    q_step_5_2_out<MODEV, PEV, T>(t, red_row, dst, st, stm);             \
+    q_step_5_2_out<CPL, MODEV, PEV, T>(t, red_row, dst, st, stm);        \
   } while (0)
     if (fast && inner) { if (pe) RQ_STEP(INNER, 1); else RQ_STEP(INNER, 0); }
     else if (fast) { if (pe) RQ_STEP(FASTM, 1); else RQ_STEP(FASTM, 0); }

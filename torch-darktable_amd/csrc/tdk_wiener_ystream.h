@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
   auto fetch = [&](int grp, int q, Raw4<T>& raw) -> bool {
     const int brow = grp / GRP_PER_ROW, x = px0 + 4 * (grp - brow * GRP_PER_ROW);
     if (!(vec && x >= 0 && x + 4 <= W)) return false;
-    raw.load4(base + (size_t)reflect_index(8 * q + brow + g.jmin * S, H) * W + x);
+    raw.load4(base + (size_t)(unsigned)reflect_index(8 * q + brow + g.jmin * S, H) * (unsigned)W + x);
     return true;
   };
   auto fetch_edge = [&](int grp, int q) -> float4 {
@@ -293,218 +293,242 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
   unsigned long long ys_acc[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long ys_t0 = __builtin_readcyclecounter();
 #endif
-  for (int i = 0; i < NB + 6; i++) {
-    // ---- inverse row stage (wave (i + 2) % 4): the block emitted in step i - 1 (slab block e = i - 6)
-    // (first in the step: its slab stores are then long complete when the step's global loads are awaited -- VMEM operations
-    // retire in order, and the compiler's conservative vmcnt(0) would otherwise expose the store latency every step)
-    if (wave == ((i + 2) & 3) && i >= 6 && !YS_ABLATE(1)) {
-      const int e = i - 6;
-      const float* src = sm.inv[(i - 1) & 1] + lane * PITCH;
-      v2f z[K];
+  // Two 8-row blocks per iteration, two phases with a barrier after each:
+  //  A (row stages): waves 0 / 1 transform blocks 2 (it - 1), 2 (it - 1) + 1 of the staging buffer forward, waves 2 / 3 take the two
+  //    blocks the column stage finished in the previous iteration through the inverse row stage to the slab -- every wave runs
+  //    exactly one row stage, so none waits for another at the barrier (one block per step with the roles rotating left two of
+  //    the four waves idle at the barrier for the length of a row stage: 19 % of a wave's time, profiles/r03);
+  //  B (column stage): every wave moves its two tile pairs down by the two blocks, then stores the samples of blocks 2 it, 2 it + 1
+  //    (their global loads were issued at the top of the phase) for the next iteration's forward stage.
+  // The hand-over buffers are single: fwd / meta are written in A and read in B, inv and the staging block in B and A.
+  const int NJ = (NB + 4) / 2 + 2;
+  const int rblk = wave & 1, sblk = wave >> 1;  // the block of the pair this wave takes in its row stage / stages
+  for (int it = 0; it < NJ; it++) {
+    // ---- phase A
+    if (wave >= 2) {
+      // inverse row stage: the block emitted in the previous iteration (slab block e)
+      const int e = 2 * it - 7 + rblk;
+      if (e >= 0 && e < NB && !YS_ABLATE(1)) {
+        const float* src = sm.inv[rblk] + lane * PITCH;
+        v2f z[K];
 #pragma unroll
-      for (int k = 0; k < K; k++) z[k] = *reinterpret_cast<const v2f*>(src + 2 * k);
-      fft_inreg_pk<32, true>(z);  // .x = row of tile a, .y = row of tile b (columns S further)
-      float s_[K + S];
+        for (int k = 0; k < K; k++) z[k] = *reinterpret_cast<const v2f*>(src + 2 * k);
+        fft_inreg_pk<32, true>(z);  // .x = row of tile a, .y = row of tile b (columns S further)
+        float s_[K + S];
 #pragma unroll
-      for (int u = 0; u < K + S; u++) {
-        float v = (u < K) ? z[u].x * WindowK<32>::w[u] : 0.0f;
-        if (u >= S) v = (u < K) ? __builtin_fmaf(z[u - S].y, WindowK<32>::w[u - S], v) : z[u - S].y * WindowK<32>::w[u - S];
-        s_[u] = v;
-      }
-      // overlap-add along x across tile pairs: pair c's samples [16, 32) belong to pair c + 1's [0, 16), its [32, 40) to
-      // pair c + 2's [0, 8) -- two and four lanes up in the 16-lane DPP row (lane = (r & 1) + 2 c + 16 (r >> 1))
-      float* srow = slab + (size_t)(8 * e + xr) * g.RSXP;
-      float tl[K - S];
-#pragma unroll
-      for (int k = 0; k < K - S; k++) {                       // the strip's last 24 columns (held by pair 7; pair 6 adds 8 of them)
-        float v = s_[2 * S + k];
-        if (k < S) v += dpp0<0x112>(s_[4 * S + k]);
-        asm volatile("" : "+v"(v));                           // keep the DPP reads out of the lane-masked branch below
-        tl[k] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < 2 * S; k += 4) {
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          o[j] = s_[k + j] + dpp0<0x112>(s_[2 * S + k + j]);        // row_shr:2
-          if (k + j < S) o[j] += dpp0<0x114>(s_[4 * S + k + j]);    // row_shr:4
+        for (int u = 0; u < K + S; u++) {
+          float v = (u < K) ? z[u].x * WindowK<32>::w[u] : 0.0f;
+          if (u >= S) v = (u < K) ? __builtin_fmaf(z[u - S].y, WindowK<32>::w[u - S], v) : z[u - S].y * WindowK<32>::w[u - S];
+          s_[u] = v;
         }
-        *reinterpret_cast<float4*>(srow + 2 * S * xc + k) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-      if (xc == NPC - 1) {
+        // overlap-add along x across tile pairs: pair c's samples [16, 32) belong to pair c + 1's [0, 16), its [32, 40) to
+        // pair c + 2's [0, 8) -- two and four lanes up in the 16-lane DPP row (lane = (r & 1) + 2 c + 16 (r >> 1))
+        float* srow = slab + (size_t)(8 * e + xr) * g.RSXP;
+        float tl[K - S];
 #pragma unroll
-        for (int k = 0; k < K - S; k += 4) *reinterpret_cast<float4*>(srow + NTC * S + k) = make_float4(tl[k], tl[k + 1], tl[k + 2], tl[k + 3]);
-      }
-    }
-
-    YS_MARK(3);  // inverse row stage
-    // ---- staging, first half: issue the global loads of block i (consumed at the bottom of the step)
-    Raw4<T> st0, st1;
-    RawRgb4<T> px[3];
-    bool pk0 = false, pk1 = false, pkx[3] = {false, false, false};
-    const int lum_half = wave == ((i + 1) & 3) ? 0 : (wave == ((i + 3) & 3) ? 1 : -1);  // LUM: this wave converts block rows 4 h .. 4 h + 3
-    if constexpr (!LUM) {
-      if (i < NB) {
-        pk0 = fetch(sg0, t0 + i, st0);
-        if (has1) pk1 = fetch(sg1, t0 + i, st1);
-      }
-    } else {
-      if (i < NB && lum_half >= 0) {
+        for (int k = 0; k < K - S; k++) {                       // the strip's last 24 columns (held by pair 7; pair 6 adds 8 of them)
+          float v = s_[2 * S + k];
+          if (k < S) v += dpp0<0x112>(s_[4 * S + k]);
+          asm volatile("" : "+v"(v));                           // keep the DPP reads out of the lane-masked branch below
+          tl[k] = v;
+        }
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-          const int grp = lane + 64 * u;  // of the 4 x 38 groups of this half block
-          if (grp < 4 * GRP_PER_ROW) {
-            const int brow = 4 * lum_half + grp / GRP_PER_ROW, x = px0 + 4 * (grp % GRP_PER_ROW);
-            if (vec_ok && x >= 0 && x + 4 <= W) {
-              px[u].load(base + ((size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W + x) * 3);
-              pkx[u] = true;
-            }
+        for (int k = 0; k < 2 * S; k += 4) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            o[j] = s_[k + j] + dpp0<0x112>(s_[2 * S + k + j]);        // row_shr:2
+            if (k + j < S) o[j] += dpp0<0x114>(s_[4 * S + k + j]);    // row_shr:4
           }
+          *reinterpret_cast<float4*>(srow + 2 * S * xc + k) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (xc == NPC - 1) {
+#pragma unroll
+          for (int k = 0; k < K - S; k += 4) *reinterpret_cast<float4*>(srow + NTC * S + k) = make_float4(tl[k], tl[k + 1], tl[k + 2], tl[k + 3]);
         }
       }
-    }
-
-    YS_MARK(0);  // staging loads issued
-    // ---- column stage: block b = i - 2 arrives; tile row t0 + b - 3 is complete from b = 3 on; after the last
-    // block the three carried blocks leave as they are (partial sums for the seam with the next strip segment)
-    const int b = i - 2;
-    if (b >= 0 && b < NB) {
-      // the window moves down one block: rows 8 .. 31 become rows 0 .. 23 (24 pair moves: cheaper than what the compiler
-      // makes of a code variant per window phase), the arriving block becomes rows 24 .. 31
-#pragma unroll
-      for (int y = 0; y < 24; y++) win[y] = win[y + 8];
-      const float* f = sm.fwd[b & 1] + col_off;
-#pragma unroll
-      for (int r = 0; r < 8; r++) win[24 + r] = *reinterpret_cast<const v2f*>(f + row_of(0, r) * PITCH);
-      if (b >= 3 && !YS_ABLATE(2)) {
-        float sa = 0.0f, sb = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float2 t = *reinterpret_cast<const float2*>(sm.meta[(b - q) & 7] + 2 * yc);
-          sa += t.x;
-          sb += t.y;
-        }
-        const float mean_a = ya ? sa * (1.0f / (K * K)) : 0.0f, mean_b = yb ? sb * (1.0f / (K * K)) : 0.0f;
-        const v2f m = {mean_a * whr - mean_b * whi, mean_a * whi + mean_b * whr};  // (mean_a + i mean_b) W[kx]
-        v2f z[32];
-#pragma unroll
-        for (int y = 0; y < 32; y++) z[y] = win_scale(y, win[y] - m);  // (R - mean W) wf[y]
-        if (!YS_ABLATE(5)) fft_inreg_pk<32, false>(z);
-        if (!YS_ABLATE(4) && !YS_ABLATE(5)) wiener_gains_pk(z, sig2);
-        if (!YS_ABLATE(5)) fft_inreg_pk<32, true>(z);
-        // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
-        const v2f ma = m * (1.0f / K);
-        {
-          v2f o[8];
-#pragma unroll
-          for (int y = 0; y < 8; y++) o[y] = win_fma(y, win_fma(y, ma, z[y]), carry[y]);
-          emit(sm.inv[i & 1] + col_off, o);
-        }
-        // the carried rows move up one block while they are updated: row y takes the sum of row y + 8.  In this order every
-        // register is read before it is rewritten; the scheduling barriers keep the order, so the move costs no copies
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 0; y < 8; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 8; y < 16; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int y = 16; y < 24; y++) carry[y] = win_scale(y + 8, win_fma(y + 8, ma, z[y + 8]));
-      }
-    } else if (b >= NB && b < NB + 3) {
-      v2f o[8];
-#pragma unroll
-      for (int y = 0; y < 8; y++) o[y] = carry[y];
-      emit(sm.inv[i & 1] + col_off, o);
-#pragma unroll
-      for (int y = 0; y < 16; y++) carry[y] = carry[y + 8];
-    }
-
-    YS_MARK(1);  // column stage
-    // ---- forward row stage (wave i % 4): block i - 1 from the staging buffer -> R rows
-    if (wave == (i & 3) && i >= 1 && i - 1 < NB && !YS_ABLATE(1)) {
-      const int bb = i - 1;
-      const float* pl = sm.plane[bb & 1] + xr * SW + 2 * S * xc;
-      float w[K + S];
-#pragma unroll
-      for (int k = 0; k < K + S; k += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(pl + k);
-        w[k] = t.x; w[k + 1] = t.y; w[k + 2] = t.z; w[k + 3] = t.w;
-      }
-      float head = 0.0f, mid = 0.0f, tail = 0.0f;
-#pragma unroll
-      for (int k = 0; k < S; k++) head += w[k];
-#pragma unroll
-      for (int k = S; k < K; k++) mid += w[k];
-#pragma unroll
-      for (int k = K; k < K + S; k++) tail += w[k];
-      // block sums under tile a / tile b: over the 8 block rows = lane bits 0, 4, 5
-      float ba = xa ? head + mid : 0.0f, bb_ = xb ? mid + tail : 0.0f;
-      ba += dpp0<0xB1>(ba); bb_ += dpp0<0xB1>(bb_);  // quad_perm [1,0,3,2]
-      ba += __shfl_xor(ba, 16, 64); bb_ += __shfl_xor(bb_, 16, 64);
-      ba += __shfl_xor(ba, 32, 64); bb_ += __shfl_xor(bb_, 32, 64);
-      if (xr == 0) *reinterpret_cast<float2*>(sm.meta[bb & 7] + 2 * xc) = make_float2(ba, bb_);
-      v2f z[K];
-      if (__builtin_amdgcn_ballot_w64(!(xa && xb)) == 0) {  // every tile of the strip exists (all strips but the last one)
-#pragma unroll
-        for (int k = 0; k < K; k++) z[k] = v2f{w[k] * WindowK<32>::w[k], w[k + S] * WindowK<32>::w[k]};
-      } else {
-        const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = 0; k < K; k++) z[k] = v2f{(w[k] * fa) * WindowK<32>::w[k], (w[k + S] * fb) * WindowK<32>::w[k]};
-      }
-      fft_inreg_pk<32, false>(z);
-      float* dst = sm.fwd[bb & 1] + lane * PITCH;
-#pragma unroll
-      for (int k = 0; k < K; k++) *reinterpret_cast<v2f*>(dst + 2 * k) = z[k];
-    }
-
-    YS_MARK(2);  // forward row stage
-    // ---- staging, second half: the samples loaded at the top go to LDS for the next step's forward row stage
-    if constexpr (!LUM) {
-      if (i < NB) {
-        float* pl = sm.plane[i & 1];
-        *reinterpret_cast<float4*>(pl + 4 * sg0) = pk0 ? st0.get() : fetch_edge(sg0, t0 + i);
-        if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = pk1 ? st1.get() : fetch_edge(sg1, t0 + i);
-      }
+      YS_MARK(3);  // inverse row stage
     } else {
-#pragma clang fp contract(off)
-      if (i < NB && lum_half >= 0) {
+      // forward row stage: block bb from the staging buffer -> R rows
+      const int bb = 2 * (it - 1) + rblk;
+      if (bb >= 0 && bb < NB && !YS_ABLATE(1)) {
+        const float* pl = sm.plane[rblk] + xr * SW + 2 * S * xc;
+        float w[K + S];
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-          const int grp = lane + 64 * u;
-          if (grp < 4 * GRP_PER_ROW) {
-            const int brow = 4 * lum_half + grp / GRP_PER_ROW, col = 4 * (grp % GRP_PER_ROW);
-            float v[12], lv[4];
-            if (pkx[u]) {
-              px[u].get(v);
-            } else {  // frame edges: reflected single pixels (or nothing beyond the last active tile), loaded here
-              const T* rowp = base + (size_t)reflect_index(8 * (t0 + i) + brow + g.jmin * S, H) * W * 3;
+        for (int k = 0; k < K + S; k += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(pl + k);
+          w[k] = t.x; w[k + 1] = t.y; w[k + 2] = t.z; w[k + 3] = t.w;
+        }
+        float head = 0.0f, mid = 0.0f, tail = 0.0f;
 #pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const bool need = col + j < sx_lim;
-                const T* q = rowp + (size_t)(need ? reflect_index(px0 + col + j, W) : 0) * 3;
-                v[3 * j] = need ? ld(q, 0) : 0.0f; v[3 * j + 1] = need ? ld(q, 1) : 0.0f; v[3 * j + 2] = need ? ld(q, 2) : 0.0f;
+        for (int k = 0; k < S; k++) head += w[k];
+#pragma unroll
+        for (int k = S; k < K; k++) mid += w[k];
+#pragma unroll
+        for (int k = K; k < K + S; k++) tail += w[k];
+        // block sums under tile a / tile b: over the 8 block rows = lane bits 0, 4, 5
+        float ba = xa ? head + mid : 0.0f, bb_ = xb ? mid + tail : 0.0f;
+        ba += dpp0<0xB1>(ba); bb_ += dpp0<0xB1>(bb_);  // quad_perm [1,0,3,2]
+        // over lane bits 4 and 5 with the gfx950 row swaps, both sums at once (the same pairs in the same order as two xor
+        // shuffles each, at VALU speed instead of four trips through the LDS crossbar).  16-lane rows of (ba | bb_):
+        // (a0 a1 a2 a3 | b0 b1 b2 b3) -- v_permlane16_swap: odd rows of the first with even rows of the second -->
+        // (a0 b0 a2 b2 | a1 b1 a3 b3), their sum (a01 b01 a23 b23); then both copies of it through v_permlane32_swap (upper half
+        // of the first with the lower half of the second): (a01 b01 a01 b01 | a23 b23 a23 b23) -> rows 0 / 2 hold the sum under
+        // tile a, rows 1 / 3 the sum under tile b.  (s_nop 1: a VALU write needs two wait states before a lane swap reads it.)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ba), "+v"(bb_));
+        float s1 = ba + bb_, s2 = s1;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s1), "+v"(s2));
+        if ((lane & 1) == 0 && lane < 32) sm.meta[bb & 7][2 * xc + (lane >> 4)] = s1 + s2;
+        v2f z[K];
+        if (__builtin_amdgcn_ballot_w64(!(xa && xb)) == 0) {  // every tile of the strip exists (all strips but the last one)
+#pragma unroll
+          for (int k = 0; k < K; k++) z[k] = v2f{w[k] * WindowK<32>::w[k], w[k + S] * WindowK<32>::w[k]};
+        } else {
+          const float fa = xa ? 1.0f : 0.0f, fb = xb ? 1.0f : 0.0f;
+#pragma unroll
+          for (int k = 0; k < K; k++) z[k] = v2f{(w[k] * fa) * WindowK<32>::w[k], (w[k + S] * fb) * WindowK<32>::w[k]};
+        }
+        fft_inreg_pk<32, false>(z);
+        float* dst = sm.fwd[rblk] + lane * PITCH;
+#pragma unroll
+        for (int k = 0; k < K; k++) *reinterpret_cast<v2f*>(dst + 2 * k) = z[k];
+      }
+      YS_MARK(2);  // forward row stage
+    }
+    __syncthreads();
+    YS_MARK(5);  // barrier
+
+    // ---- phase B, once per block of the pair: issue the global loads of the samples of block qs = 2 it + blk, run the column stage
+    // on block b = 2 (it - 1) + blk (tile row t0 + b - 3 is complete from b = 3 on; after the last block the three carried blocks
+    // leave as they are: partial sums for the seam with the next strip segment), then store the samples for the next iteration's
+    // forward row stage (a wave's share: 76 groups of 4 samples; LUM: waves 0 / 1 convert block rows 0 .. 3 / 4 .. 7 in the round
+    // of block 0, waves 2 / 3 in the round of block 1)
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+      const int b = 2 * (it - 1) + blk;
+      const int qs = 2 * it + blk;
+      Raw4<T> st0, st1;
+      RawRgb4<T> px[3];
+      bool pk0 = false, pk1 = false, pkx[3] = {false, false, false};
+      if constexpr (!LUM) {
+        if (qs < NB) {
+          pk0 = fetch(sg0, t0 + qs, st0);
+          if (has1) pk1 = fetch(sg1, t0 + qs, st1);
+        }
+      } else {
+        if (qs < NB && sblk == blk) {
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const int grp = lane + 64 * u;  // of the 4 x 38 groups of this half block
+            if (grp < 4 * GRP_PER_ROW) {
+              const int brow = 4 * rblk + grp / GRP_PER_ROW, x = px0 + 4 * (grp % GRP_PER_ROW);
+              if (vec_ok && x >= 0 && x + 4 <= W) {
+                px[u].load(base + ((size_t)reflect_index(8 * (t0 + qs) + brow + g.jmin * S, H) * W + x) * 3);
+                pkx[u] = true;
               }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {  // same expression as lum_extract_vec4 (color.hip)
-              const float yv = YS_ABLATE(3) ? v[3 * j] + v[3 * j + 1] + v[3 * j + 2] : cA::rgb_to_lab_l(clip3(mk3(v[3 * j], v[3 * j + 1], v[3 * j + 2])));
-              lv[j] = YS_ABLATE(3) ? yv : tdk_log(fmaxf(lum_eps, yv));
-            }
-            *reinterpret_cast<float4*>(sm.plane[i & 1] + brow * SW + col) = make_float4(lv[0], lv[1], lv[2], lv[3]);
           }
         }
       }
+      YS_MARK(0);  // staging loads issued
+      if (b >= 0 && b < NB) {
+        // the window moves down one block: rows 8 .. 31 become rows 0 .. 23 (24 pair moves: cheaper than what the compiler
+        // makes of a code variant per window phase), the arriving block becomes rows 24 .. 31
+#pragma unroll
+        for (int y = 0; y < 24; y++) win[y] = win[y + 8];
+        const float* f = sm.fwd[blk] + col_off;
+#pragma unroll
+        for (int r = 0; r < 8; r++) win[24 + r] = *reinterpret_cast<const v2f*>(f + row_of(0, r) * PITCH);
+        if (b >= 3 && !YS_ABLATE(2)) {
+          float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float2 t = *reinterpret_cast<const float2*>(sm.meta[(b - q) & 7] + 2 * yc);
+            sa += t.x;
+            sb += t.y;
+          }
+          const float mean_a = ya ? sa * (1.0f / (K * K)) : 0.0f, mean_b = yb ? sb * (1.0f / (K * K)) : 0.0f;
+          const v2f m = {mean_a * whr - mean_b * whi, mean_a * whi + mean_b * whr};  // (mean_a + i mean_b) W[kx]
+          v2f z[32];
+#pragma unroll
+          for (int y = 0; y < 32; y++) z[y] = win_scale(y, win[y] - m);  // (R - mean W) wf[y]
+          if (!YS_ABLATE(5)) fft_inreg_pk<32, false>(z);
+          if (!YS_ABLATE(4) && !YS_ABLATE(5)) wiener_gains_pk(z, sig2);
+          if (!YS_ABLATE(5)) fft_inreg_pk<32, true>(z);
+          // (v + mean wf[y] W[kx]) * wi[y], in units of 1/32 (the inverse row pass is unscaled); overlap-add across tile rows
+          const v2f ma = m * (1.0f / K);
+          {
+            v2f o[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) o[y] = win_fma(y, win_fma(y, ma, z[y]), carry[y]);
+            emit(sm.inv[blk] + col_off, o);
+          }
+          // the carried rows move up one block while they are updated: row y takes the sum of row y + 8.  In this order every
+          // register is read before it is rewritten; the scheduling barriers keep the order, so the move costs no copies
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int y = 0; y < 8; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int y = 8; y < 16; y++) carry[y] = win_fma(y + 8, win_fma(y + 8, ma, z[y + 8]), carry[y + 8]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int y = 16; y < 24; y++) carry[y] = win_scale(y + 8, win_fma(y + 8, ma, z[y + 8]));
+        }
+      } else if (b >= NB && b < NB + 3) {
+        v2f o[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) o[y] = carry[y];
+        emit(sm.inv[blk] + col_off, o);
+#pragma unroll
+        for (int y = 0; y < 16; y++) carry[y] = carry[y + 8];
+      }
+      YS_MARK(1);  // column stage
+
+      // ---- staging, second half: the samples loaded at the top of the round go to LDS for the next iteration's forward row stage
+      if constexpr (!LUM) {
+        if (qs < NB) {
+          float* pl = sm.plane[blk];
+          *reinterpret_cast<float4*>(pl + 4 * sg0) = pk0 ? st0.get() : fetch_edge(sg0, t0 + qs);
+          if (has1) *reinterpret_cast<float4*>(pl + 4 * sg1) = pk1 ? st1.get() : fetch_edge(sg1, t0 + qs);
+        }
+      } else {
+#pragma clang fp contract(off)
+        if (qs < NB && sblk == blk) {
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const int grp = lane + 64 * u;
+            if (grp < 4 * GRP_PER_ROW) {
+              const int brow = 4 * rblk + grp / GRP_PER_ROW, col = 4 * (grp % GRP_PER_ROW);
+              float v[12], lv[4];
+              if (pkx[u]) {
+                px[u].get(v);
+              } else {  // frame edges: reflected single pixels (or nothing beyond the last active tile), loaded here
+                const T* rowp = base + (size_t)reflect_index(8 * (t0 + qs) + brow + g.jmin * S, H) * W * 3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  const bool need = col + j < sx_lim;
+                  const T* q = rowp + (size_t)(need ? reflect_index(px0 + col + j, W) : 0) * 3;
+                  v[3 * j] = need ? ld(q, 0) : 0.0f; v[3 * j + 1] = need ? ld(q, 1) : 0.0f; v[3 * j + 2] = need ? ld(q, 2) : 0.0f;
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; j++) {  // same expression as lum_extract_vec4 (color.hip)
+                const float yv = YS_ABLATE(3) ? v[3 * j] + v[3 * j + 1] + v[3 * j + 2] : cA::rgb_to_lab_l(clip3(mk3(v[3 * j], v[3 * j + 1], v[3 * j + 2])));
+                lv[j] = YS_ABLATE(3) ? yv : tdk_log(fmaxf(lum_eps, yv));
+              }
+              *reinterpret_cast<float4*>(sm.plane[blk] + brow * SW + col) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+            }
+          }
+        }
+      }
+      // Every global operation of the round has retired by now (the slab stores were issued in phase A, the loads are consumed
+      // just above).  Saying so explicitly keeps the compiler from placing its own vmcnt(0) at the top of the next round or behind
+      // the next iteration's slab stores, where it would expose their latency (its scoreboard cannot see that the load and the
+      // use of the staging registers sit under the same condition).
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+      YS_MARK(4);  // staging conversion / store
     }
-    // Every global operation of the step has retired by now (the stores were issued at its top, the loads are consumed just
-    // above).  Saying so explicitly keeps the compiler from placing its own vmcnt(0) at the top of the next step, right
-    // behind the next slab stores, where it would expose their latency (its scoreboard cannot see that the load and
-    // the use of the staging registers sit under the same condition).
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-    YS_MARK(4);  // staging conversion / store
     __syncthreads();
     YS_MARK(5);  // barrier
     YS_MARK(6);  // nothing: the cost of a mark itself

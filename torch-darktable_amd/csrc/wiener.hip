@@ -90,9 +90,8 @@ struct Geom {
 };
 
 __device__ __forceinline__ int reflect_index(int x, int limit) {
-  if (x < 0) x = -x;
-  if (x >= limit) x = 2 * limit - x - 1;
-  return x;
+  x = x < 0 ? -x : x;
+  return min(x, 2 * limit - 1 - x);  // == (x >= limit) ? 2 * limit - x - 1 : x, without the select
 }
 
 // x <- (lane is one of the slot's two self-conjugate lanes) ? x : x of lane ^ 1: v_mov_b32_dpp + v_cndmask_b32_e64

@@ -39,6 +39,7 @@ class FrameStreams:
         self.device = device
         self.chains = [make_chain() for _ in range(streams)]
         self.streams = [torch.cuda.Stream(device) for _ in range(streams)] if streams > 1 else [None]
+        self._next = 0  # the stream the next frame goes to: the rotation carries over from batch to batch
 
     def issue(self, frames) -> list:
         """Launch every frame's chain; returns the outputs without joining the streams (they are complete only after
@@ -52,9 +53,11 @@ class FrameStreams:
         for s in self.streams:
             s.wait_stream(here)  # the inputs were produced on the caller's stream
         n = len(self.streams)
-        for i, f in enumerate(frames):
-            with torch.cuda.stream(self.streams[i % n]):
-                outs.append(self.chains[i % n](f))
+        for f in frames:
+            k = self._next
+            self._next = (k + 1) % n
+            with torch.cuda.stream(self.streams[k]):
+                outs.append(self.chains[k](f))
         return outs
 
     def join(self, outs=()) -> None:
