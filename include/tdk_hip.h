@@ -82,6 +82,10 @@ int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height
  * walked down the frame (csrc/tdk_rcd_stream.h), the others as 64 x 64 LDS tiles; TDK_RCD_TILE_KERNEL takes the tile kernel
  * for any frame.  Both give the same bits (the GPU tests compare them through this flag); nothing is process-global. */
 #define TDK_RCD_TILE_KERNEL 1u
+/* TDK_RCD_CONCURRENT: the caller keeps other kernels in flight on other streams (several frames at once).  The column strips
+ * then run as their register-blocked variant (csrc/tdk_rcd_quad.h): the same bits on half the waves per CU, which is slower
+ * with the GPU to itself and faster for the whole when other frames' kernels can use the wave slots and registers it leaves. */
+#define TDK_RCD_CONCURRENT 2u
 int tdk_rcd_ex(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, unsigned flags,
                tdk_stream_t stream);
 

@@ -27,7 +27,8 @@ ALLOWED_EXTRA_METHODS = {
 # extra module-level names: the metrics accumulator, the pipeline's normalise kernel, the reference's own create_wiener
 # helper (denoise.py:112) and the exception type the reference registers
 ALLOWED_EXTRA_NAMES = {'MetricsAccumulator', 'normalize_image', 'create_wiener', 'JpegException',
-                       'verification_paths'}  # thread-local context the GPU tests use to ask for an op's second kernel path
+                       'verification_paths',  # thread-local context the GPU tests use to ask for an op's second kernel path
+                       'concurrent_frames'}   # thread-local context: other frames' kernels are in flight on other streams (sharding.FrameStreams)
 
 
 @pytest.fixture(scope='module')

@@ -80,8 +80,11 @@ def test_rcd_strips_equal_tiles_on_whole_frames(td, dev, shape):
             strips = ws.process(x)
             with ext.verification_paths(rcd_tiles=True):
                 tiles = ws.process(x)
+            with ext.concurrent_frames():  # the register-blocked strips (TDK_RCD_CONCURRENT)
+                quad = ws.process(x)
             assert torch.equal(strips, tiles), f'{shape} {pattern} {x.dtype}: {(strips != tiles).sum().item()} values differ'
-            del strips, tiles
+            assert torch.equal(quad, tiles), f'{shape} {pattern} {x.dtype}, register-blocked strips: {(quad != tiles).sum().item()} values differ'
+            del strips, tiles, quad
 
 
 def test_ppg_bilinear_12mp_crop_consistency(td, oracle, dev, frame12):

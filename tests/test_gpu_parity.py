@@ -133,7 +133,10 @@ def test_rcd_strips_equal_tiles(td, oracle, dev, scene, pattern, size):
     from torch_darktable import torch_darktable_extension as ext
     with ext.verification_paths(rcd_tiles=True):
         tiles, tiles16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
-    for name, got, want in (('strips', strips, ref), ('tiles', tiles, ref), ('strips f16', strips16, ref16), ('tiles f16', tiles16, ref16)):
+    with ext.concurrent_frames():  # the register-blocked strips (csrc/tdk_rcd_quad.h, TDK_RCD_CONCURRENT)
+        quad, quad16 = npy(ws.process(gpu(bayer, dev))), npy(ws.process(gpu(b16, dev)))
+    for name, got, want in (('strips', strips, ref), ('tiles', tiles, ref), ('strips f16', strips16, ref16), ('tiles f16', tiles16, ref16),
+                            ('quad strips', quad, ref), ('quad strips f16', quad16, ref16)):
         bad = np.argwhere(got != want)
         assert bad.size == 0, f'{name}: {len(bad)} mismatches, first at {bad[:5].tolist()}'
 
@@ -154,7 +157,10 @@ def test_rcd_strips_equal_tiles_on_many_geometries(td, dev):
         strips = ws.process(bayer)
         with ext.verification_paths(rcd_tiles=True):
             tiles = ws.process(bayer)
+        with ext.concurrent_frames():
+            quad = ws.process(bayer)
         assert torch.equal(strips, tiles), f'{w}x{h} {pattern}: {(strips != tiles).sum().item()} values differ'
+        assert torch.equal(quad, tiles), f'{w}x{h} {pattern}, register-blocked strips: {(quad != tiles).sum().item()} values differ'
 
 
 @pytest.mark.parametrize('size', [(2, 2), (2, 4), (4, 4), (4, 6), (6, 8), (10, 14), (14, 16), (16, 16), (7, 5), (3, 64), (64, 2)])

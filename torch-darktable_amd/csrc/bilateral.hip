@@ -774,6 +774,9 @@ int launch_tiles(const TL* lum, const T* rgb, T* out, int* tab, int width, int h
                  const TileLds& L, size_t lds_bytes, bool vec, bool prepared, hipStream_t s) {
   const int tiles_x = tdk_div_up(width, FTW), tiles_y = tdk_div_up(height, FTH), ntiles = tiles_x * tiles_y;
   const dim3 grid(8 * tdk_div_up(ntiles, 8));
+#ifdef TDK_EXPERIMENTS
+  if (const char* e = getenv("TDK_BIL_LDS_PAD")) lds_bytes += (size_t)atoi(e);  // fewer resident workgroups per CU (co-residency experiment)
+#endif
   if (!prepared) {  // the tables depend on the geometry and the sigmas only: a caller that keeps its workspace builds them once (tdk_bilateral_prepare)
     const int rc = build_tables(tab, width, height, d, sigma_s, L, s);
     if (rc != TDK_OK) return rc;

@@ -663,12 +663,15 @@ __device__ __forceinline__ bool load_tile(const TI* __restrict__ in, int w, int 
 }
 
 #include "tdk_rcd_stream.h"
-#ifdef TDK_EXPERIMENTS
-// the register-blocked strips (a lane owns four columns, own-column 16-byte LDS reads, neighbour taps by DPP): bit-exact on
-// every RCD test, 55 % fewer LDS and 6 % fewer VALU instructions than rs::rcd_stream -- and 12 % slower (183 against 164 us),
-// because half-wave rows leave 12 instead of 24 waves per CU in the same LDS (profiles/r04/experiments/rcd_quad.txt).
+// The register-blocked strips (a lane owns four columns, own-column 16-byte LDS reads, neighbour taps by DPP): the same bits as
+// rs::rcd_stream with 55 % fewer LDS and 6 % fewer VALU instructions, on HALF the waves (half-wave rows: 12 waves per CU in the
+// same LDS, 112 VGPRs each).  With the GPU to itself it is 12 % slower than rs::rcd_stream (183 against 164 us: three waves per
+// SIMD no longer cover the dependent chains, profiles/r04/experiments/rcd_quad.txt); with other frames' kernels in flight on
+// other streams it is the faster choice for the whole (+3 % frames per second on the 12 MP chain,
+// profiles/r04/experiments/coresidency.txt): it leaves five wave slots and 176 VGPRs per SIMD, where the streaming kernels of
+// the other frames (luminance, Wiener finish, tone map, metrics: 150 us per frame) run next to it instead of after it.
+// Callers that keep several frames in flight ask for it with TDK_RCD_CONCURRENT.
 #include "tdk_rcd_quad.h"
-#endif
 
 // Persistent workgroups (one per CU: the five planes fill its LDS).  Work list: `nborder` chunks of the border
 // ring (independent of the tiles: disjoint output pixels, input read-only), then the tiles; workgroup b takes
@@ -753,6 +756,7 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
 #ifdef TDK_EXPERIMENTS
       if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
 #endif
+      bool quad = (flags & TDK_RCD_CONCURRENT) != 0;
 #ifdef TDK_EXPERIMENTS
       if (const char* e = getenv("TDK_RCD_QUAD")) {  // columns per lane of the register-tap variant: 2, else 4
         if (atoi(e) == 2) {
@@ -761,12 +765,15 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
           TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<2, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<2>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
           return TDK_OK;
         }
+        quad = atoi(e) != 0;
+      }
+#endif
+      if (quad) {
         const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<4, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
         if (rcq != TDK_OK) return rcq;
         TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<4, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<4>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
         return TDK_OK;
       }
-#endif
       const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
       if (rc != TDK_OK) return rc;
       TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
@@ -800,7 +807,7 @@ TDK_EXPORT int tdk_rcd_ex(const void* bayer, void* rgb, void* /*workspace*/, int
   TDK_REQUIRE((width & 1) == 0, "tdk_rcd: width must be even (the reference packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
               "tdk_rcd: invalid Bayer pattern 0x%08x", pattern);
-  TDK_REQUIRE((flags & ~TDK_RCD_TILE_KERNEL) == 0, "tdk_rcd: unknown flags 0x%x", flags);
+  TDK_REQUIRE((flags & ~(TDK_RCD_TILE_KERNEL | TDK_RCD_CONCURRENT)) == 0, "tdk_rcd: unknown flags 0x%x", flags);
   TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, flags, tdk_stream(stream)));
   return TDK_OK;
 }

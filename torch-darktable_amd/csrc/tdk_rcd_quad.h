@@ -6,9 +6,7 @@
 // workgroup owns a strip of 108 output columns (128 computed), walks DOWN the frame 8 rows per step, every step runs its
 // vertical tap reach behind the newest CFA row on sliding linear LDS planes.  What changes is who reads what:
 //  * rs: wave = row, lane = column PAIR, planes de-interleaved by column parity; every tap is its own 4-byte LDS read (148 per
-//    lane and step, 74 per pixel).  Round 4's counters (profiles/r04/rcd_pmc_*.txt): LDS instructions active 70 % of the
-//    kernel, 17 % of all wave cycles stalled on LDS issue -- while 10 % fewer VALU instructions changed nothing.  The kernel
-//    is bound by LDS instruction throughput (a 4-byte read moves 75-128 B/clk, a 16-byte one 160-256).
+//    lane and step, 74 per pixel), 24 waves per CU.
 //  * here: half a wave = one row, lane = columns 4 q .. 4 q + 3, planes in natural column order.  A lane reads ONLY ITS OWN
 //    columns: one ds_read_b128 per plane row it touches (one ds_read_b64 of the compacted half-density planes), whatever the
 //    number of taps in that row; the taps of the neighbour columns (reach <= 4 = one quad) come from the neighbour lanes'
@@ -17,7 +15,13 @@
 //  * the two halves of a wave take rows r and r + 4 of the 8-row block (same CFA phase, so the R/B column parity stays a
 //    compile-time constant of the wave's code variant); a shift that crosses lane 31 | 32 brings a value of the other row --
 //    into the outermost halo columns only, which hold garbage by construction (they read beyond the window in rs as well).
-//  * 256-thread workgroups (4 waves x 2 rows), the same 47 KB of planes: three workgroups per CU, 168 VGPRs per lane.
+//  * 256-thread workgroups (4 waves x 2 rows), the same 47 KB of planes: three workgroups per CU = 12 waves, 104-112 VGPRs.
+// Measured (profiles/r04/experiments/rcd_quad.txt, coresidency.txt): 45 % of rs's LDS and 94 % of its VALU instructions, the same
+// bits on all RCD tests; alone on the GPU 183 us against 164 (three waves per SIMD do not cover the dependent chains of the exact
+// divisions), but with other frames in flight on other streams the chain gains 3 %: the wave slots and registers this kernel
+// leaves (5 slots, 176 VGPRs per SIMD) take the streaming kernels of the other frames.  Selected by TDK_RCD_CONCURRENT.
+// CPL = 2 (a lane owns two columns, a wave a row, 24 waves per CU: experiments only) needs two DPP hops for the far taps and lost
+// on both counts (profiles/r04/experiments/rcd_pair_dpp.txt).
 #pragma once
 
 namespace rq {

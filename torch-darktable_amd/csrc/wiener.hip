@@ -694,7 +694,15 @@ template <typename T>
 int launch_tiles_ys(const T* in, float* slabs, int W, int H, int C, int c, const float* sigmas, const Geom& g, hipStream_t st_, int nplanes) {
   const int vec_ok = W % 4 == 0 && (C == 1 ? tdk_aligned(in, 4 * sizeof(T)) : (C == 3 && tdk_aligned(in, 16)));
   static const ys::YParams yp = make_yparams();
-  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T, false>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(256), 0, st_, in, slabs, W, H, C, c, vec_ok, g, sigmas,
+  size_t lds_pad = 0;
+#ifdef TDK_EXPERIMENTS
+  if (const char* e = getenv("TDK_WIENER_LDS_PAD")) {  // one resident workgroup per CU (co-residency experiment)
+    lds_pad = (size_t)atoi(e);
+    const int rcl = tdk_raise_lds_limit(reinterpret_cast<const void*>(&ys::wiener_ystream<T, false>), 160 * 1024 - (int)sizeof(ys::Smem), "tdk_wiener(hipFuncSetAttribute)");
+    if (rcl != TDK_OK) return rcl;
+  }
+#endif
+  TDK_LAUNCH("tdk_wiener(tiles)", (ys::wiener_ystream<T, false>), dim3((unsigned)(g.ngx * g.ngy * nplanes)), dim3(256), lds_pad, st_, in, slabs, W, H, C, c, vec_ok, g, sigmas,
              yp, C == 1 ? (size_t)W * H : (size_t)0, 0.0f);
   return TDK_OK;
 }

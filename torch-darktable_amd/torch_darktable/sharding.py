@@ -52,12 +52,15 @@ class FrameStreams:
         here = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(here)  # the inputs were produced on the caller's stream
+        from .torch_darktable_extension import concurrent_frames
+
         n = len(self.streams)
-        for f in frames:
-            k = self._next
-            self._next = (k + 1) % n
-            with torch.cuda.stream(self.streams[k]):
-                outs.append(self.chains[k](f))
+        with concurrent_frames():  # the other streams' frames share the GPU with every kernel launched here
+            for f in frames:
+                k = self._next
+                self._next = (k + 1) % n
+                with torch.cuda.stream(self.streams[k]):
+                    outs.append(self.chains[k](f))
         return outs
 
     def join(self, outs=()) -> None:

@@ -54,7 +54,7 @@ class BayerPattern(enum.IntEnum):
 # Two ops have a second kernel path that gives the same bits (RCD: 64 x 64 LDS tiles instead of the column strips; Bilateral:
 # the four-kernel path instead of the LDS tile kernel).  The library selects per call (the `flags` of tdk_rcd_ex /
 # tdk_bilateral_ex); this thread-local context is how the GPU tests ask for the other path.  Nothing is process-global.
-TDK_RCD_TILE_KERNEL, TDK_BILATERAL_PREPARED, TDK_BILATERAL_GENERAL_PATH = 1, 1, 2
+TDK_RCD_TILE_KERNEL, TDK_RCD_CONCURRENT, TDK_BILATERAL_PREPARED, TDK_BILATERAL_GENERAL_PATH = 1, 2, 1, 2
 _verify = threading.local()
 
 
@@ -68,6 +68,20 @@ def verification_paths(rcd_tiles: bool = False, bilateral_general: bool = False)
     yield
   finally:
     _verify.rcd, _verify.bil = old
+
+
+@contextlib.contextmanager
+def concurrent_frames(on: bool = True):
+  """Inside the context (this thread only) the ops are told that other frames' kernels are in flight on other streams
+  (TDK_RCD_CONCURRENT: RCD.process takes the strips variant that runs on half the waves per CU -- the same bits, slower alone,
+  faster for the whole when the other frames' kernels can use what it leaves).  sharding.FrameStreams enters it for the frames
+  it spreads over more than one stream."""
+  old = getattr(_verify, 'concurrent', 0)
+  _verify.concurrent = TDK_RCD_CONCURRENT if on else 0
+  try:
+    yield
+  finally:
+    _verify.concurrent = old
 
 
 # ------------------------------------------------------------------ helpers
@@ -249,7 +263,7 @@ class RCD(_Workspace):
     self._check_size(x)
     out = torch.empty((self._height, self._width, 3), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-      check(lib.tdk_rcd_ex(_ptr(x), _ptr(out), None, self._width, self._height, self._pattern, _dtype_tag(x), getattr(_verify, 'rcd', 0), _stream()))
+      check(lib.tdk_rcd_ex(_ptr(x), _ptr(out), None, self._width, self._height, self._pattern, _dtype_tag(x), getattr(_verify, 'rcd', 0) | getattr(_verify, 'concurrent', 0), _stream()))
     return out
 
 
