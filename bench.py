@@ -211,7 +211,7 @@ class Ranks:
 def stages(workload: str, s: int):
     if workload == 'isp':
         return {
-            'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(border)']),
+            'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(concurrent)', 'tdk_rcd(border)']),
             'denoise': (3 * s + 3 * s, ['tdk_compute_luminance', 'tdk_wiener(tiles)', 'tdk_wiener(finish+modify)']),
             'local_contrast': (3 * s + 3 * s, ['tdk_bilateral(tiles)', 'tdk_bilateral(tables)', 'tdk_bilateral(slice+modify)', 'tdk_bilateral(splat)',
                                                 'tdk_bilateral(blur_xy)', 'tdk_bilateral(blur_z)']),
@@ -235,6 +235,7 @@ def stage_of(kernel: str, workload: str, s: int):
 def launch_bytes_per_px(kernel: str, s: int) -> float | None:
     table = {
         'tdk_rcd': 1 * s + 3 * s,
+        'tdk_rcd(concurrent)': 1 * s + 3 * s,                  # the register-blocked strips (frames in flight on other streams)
         'tdk_ppg': 1 * s + 3 * s,
         'tdk_compute_luminance': 3 * s + 4,                    # RGB in, fp32 (log-)lightness plane out
         'tdk_wiener(tiles)': 4 + 4,                            # fp32 plane in, the denoised plane's sums out (fp32 slabs)
@@ -459,10 +460,13 @@ def main(argv=None):
     inputs = [synthetic_bayer(h, w, seed=1234 + rank * frames + i, device=dev).to(dtype) for i in range(frames)]
     torch.cuda.synchronize()
 
-    def step_serial():  # every frame on the current stream: the per-kernel table comes from this
+    def step_serial():  # every frame on the current stream: the per-kernel table comes from this (the kernels the timed region runs)
+        import contextlib
+        from torch_darktable.torch_darktable_extension import concurrent_frames
         out = None
-        for b in inputs:
-            out = process(b)
+        with (concurrent_frames() if nstreams > 1 else contextlib.nullcontext()):
+            for b in inputs:
+                out = process(b)
         return out
 
     last = [None]

@@ -39,6 +39,7 @@ KERNELS = {
     'rcd_interior': ('tdk_rcd', False),
     # column strips: one 4-B (fp16) / 8-B (fp32) sample pair per lane and step, 12-B / 24-B pixel pairs out
     'rcd_stream': ('tdk_rcd', False),
+    'rcd_quad': ('tdk_rcd(concurrent)', False),  # register-blocked strips (TDK_RCD_CONCURRENT): same loads and stores
     'rcd_border': ('tdk_rcd(border)', False),
     'bilateral_tile_kernel': ('tdk_bilateral(tiles)', True),
     'bilateral_axis_tables_kernel': ('tdk_bilateral(tables)', False),

@@ -62,8 +62,9 @@ def main():
             td.reinhard_tonemap(rgb, metrics, params)
         elif a.op == 'luminance':
             td.modify_luminance(rgb, td.compute_luminance(rgb))
-        elif a.op == 'isp':  # the chain bench.py times (with its stage hand-overs)
-            x = rcd.process(bayer)
+        elif a.op == 'isp':  # the chain bench.py times (with its stage hand-overs; the kernels it runs with frames on several streams)
+            with td.torch_darktable_extension.concurrent_frames():
+                x = rcd.process(bayer)
             x = wiener.process_log_luminance(x, 0.075, luminance_out=lum_plane)
             x = bil.process_rgb(x, 0.4, luminance=lum_plane, metrics=acc)
             td.reinhard_tonemap(x, acc.finish(), params)

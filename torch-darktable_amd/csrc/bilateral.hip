@@ -446,7 +446,10 @@ __device__ __forceinline__ void sample_gz(const float (&v)[N], float (&g)[N], fl
 
 // MODE 0: luminance plane in (TL == T) -> filtered plane out; 1 / 2: fp32 plane + RGB in -> RGB out (linear / log)
 template <typename TL, typename T, int MODE, int VEC>
-__global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(8, 8))) void bilateral_tile_kernel(
+#ifndef TDK_BIL_WPE
+#define TDK_BIL_WPE 8  // waves per SIMD the register budget is set for (experiments: co-residency with other frames' kernels)
+#endif
+__global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(TDK_BIL_WPE, TDK_BIL_WPE))) void bilateral_tile_kernel(
     const TL* __restrict__ lum, const T* __restrict__ rgb, T* __restrict__ out, const int* __restrict__ tab, int width, int height, GridDims d,
     float sigma_r, int tiles_x, int ntiles, TileLds L) {
   extern __shared__ float smem[];

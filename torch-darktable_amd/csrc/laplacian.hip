@@ -37,7 +37,11 @@ namespace {
 constexpr int NG = 6;
 constexpr int NP = NG + 1;  // pyramids that are reduced: the input's and the six gammas'
 constexpr int MAX_LEVELS = 30;
-constexpr int DEEP_PIXELS = 32768;  // levels at most this large are handled inside single workgroups
+constexpr int DEEP_PIXELS = 32768;  // levels at most this large are reduced inside single workgroups (one per pyramid)
+// ... and levels at most this large assembled by ONE workgroup: the assemble has a single output pyramid, so its single-workgroup
+// form pays for every pixel with one 1024-thread workgroup's latency -- level 5 of a 12 MP frame (13 K pixels to assemble) took
+// 30 of that launch's 47 us and takes 11 as a tiled launch of its own
+constexpr int DEEP_ASSEMBLE_PIXELS = 8192;
 
 inline int dl(int x, int level) { return (x + (1 << level) - 1) >> level; }
 
@@ -256,7 +260,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(Layout L, int l) {
 // rounded to binary16 like the stored level, stores the 32 x 32 cells of level l + 1 it owns, and reduces the window to
 // its level-(l+2) cells.  Window cell (wr, wc) holds level l + 1 at (2 Y0 - 4 + wr, 2 X0 - 4 + wc) clamped into the level:
 // every tap the centre clamp can ask for is inside.
-constexpr int P_T = 16, P_WIN = 2 * P_T + 6, P_WS = P_WIN + 1, P_FW = 2 * P_WIN + 3, P_FS = P_FW + 1;  // 38, 39, 79, 80
+constexpr int P_T = 16, P_WIN = 2 * P_T + 6, P_WS = P_WIN + 1, P_FW = 2 * P_WIN + 3, P_FQ = (P_FW + 4) / 4;  // 38, 39, 79, 20 quads per row
+// row pitch of the staged fine cells in halves.  (With this natural pitch lanes 38 .. 63 of a wave collide two-way with lanes
+// 0 .. 37 -- 42 % of the kernel's LDS cycles are bank conflicts; a pitch of 104 removes them and changes nothing, 72.6 against
+// 69.4 us: the kernel waits on its three dependent phases, not on the LDS.  profiles/r04/experiments/laplacian_small_levels.txt)
+constexpr int P_FS = 80;
+static_assert(P_FS >= 4 * P_FQ && P_FS % 4 == 0, "8-byte staging stores");
 
 __global__ __launch_bounds__(256) void reduce_pair_kernel(Layout L, int l) {
   __shared__ __align__(8) __half fwin[P_FW * P_FS];
@@ -273,8 +282,8 @@ __global__ __launch_bounds__(256) void reduce_pair_kernel(Layout L, int l) {
   const int fx0 = 2 * clampc(into(ox, w1), w1) - 2, fx1 = 2 * clampc(into(ox + P_WIN - 1, w1), w1) + 2;
   const int fy0 = 2 * clampc(into(oy, h1), h1) - 2, fy1 = 2 * clampc(into(oy + P_WIN - 1, h1), h1) + 2;
   if (fx1 - fx0 == P_FW - 1 && fy1 - fy0 == P_FW - 1) {  // full window: 4 cells per load (the 80th column is read but never used)
-    for (int i = threadIdx.x; i < P_FW * (P_FS / 4); i += 256) {
-      const int r = i / (P_FS / 4), q = i - r * (P_FS / 4);
+    for (int i = threadIdx.x; i < P_FW * P_FQ; i += 256) {
+      const int r = i / P_FQ, q = i - r * P_FQ;
       uint2 u;
       __builtin_memcpy(&u, fine + (size_t)(fy0 + r) * fw + fx0 + 4 * q, 8);
       *reinterpret_cast<uint2*>(&fwin[r * P_FS + 4 * q]) = u;
@@ -517,10 +526,11 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
                          lo(clamp_boundary(f.y0, fh) / 2 - 1), (clamp_boundary(f.y1, fh) / 2 + 1 < chh - 1) ? clamp_boundary(f.y1, fh) / 2 + 1 : chh - 1};
   }
   int a = top - 1;  // next level to assemble (the coarsest output level is the coarsest input level)
-  if (a >= 1 && small(a)) {
+  auto small_a = [&](int l) { return (int64_t)L.lw(l) * L.lh(l) <= DEEP_ASSEMBLE_PIXELS; };
+  if (a >= 1 && small_a(a)) {
     int bottom = a;
     auto fits = [&](int lv) { return (size_t)NP * L.lw(lv + 1) * L.lh(lv + 1) * sizeof(__half) <= 150 * 1024; };  // its coarser level in LDS, 7 pyramids
-    while (bottom - 1 >= 1 && small(bottom - 1) && fits(bottom - 1)) bottom--;
+    while (bottom - 1 >= 1 && small_a(bottom - 1) && fits(bottom - 1)) bottom--;
     const size_t lds = (size_t)NP * L.lw(bottom + 1) * L.lh(bottom + 1) * sizeof(__half);  // the largest coarser level staged
     TDK_MAX_LDS_ONCE(deep_assemble_kernel, "tdk_laplacian(hipFuncSetAttribute)");
     TDK_LAUNCH("tdk_laplacian(deep assemble)", deep_assemble_kernel, dim3(1), dim3(1024), lds, s, L, need, a, bottom);

@@ -771,7 +771,7 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       if (quad) {
         const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<4, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
         if (rcq != TDK_OK) return rcq;
-        TDK_LAUNCH("tdk_rcd", (rq::rcd_quad<4, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<4>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+        TDK_LAUNCH("tdk_rcd(concurrent)", (rq::rcd_quad<4, TI, T>), dim3((unsigned)nwg), dim3(rq::Geo<4>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
         return TDK_OK;
       }
       const int rc = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
