@@ -23,6 +23,10 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -o s -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq2.log 2>&1 || echo "sq2 pass failed (optional)"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/sq3 -o t -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq3.log 2>&1 || echo "sq3 pass failed (optional)"
 python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json $OUT/valu $GIT $OUT/sq2 $OUT/sq3 > $OUT/traffic.log 2>&1 || exit 1
+# the bench line again, now that the counters of these sources exist (roofline.valu / roofline.composite need them)
+cp $OUT/traffic.json profiles/traffic.json
+python3 bench.py --steps 10 --warmup 3 > $OUT/bench_isp_plain.json 2> $OUT/bench_isp_plain.err || exit 1
+python3 bench.py --steps 10 --warmup 3 --streams 2 --no-cpu-baseline > $OUT/bench_isp_streams2_plain.json 2> $OUT/bench_isp_streams2_plain.err || echo "streams 2 failed"
 python3 profiles/op_bench.py --storage f16 > $OUT/op_bench_f16.json 2> $OUT/op_bench_f16.err || echo "op bench f16 failed"
 python3 profiles/op_bench.py --storage f32 > $OUT/op_bench_f32.json 2> $OUT/op_bench_f32.err || echo "op bench f32 failed"
 python3 profiles/op_bench.py --storage f16 --width 8192 --height 6144 --only "PPG|Wiener.process C=3" > $OUT/op_bench_50mp_f16.json 2> $OUT/op_bench_50mp_f16.err || echo "op bench 50 MP failed"
