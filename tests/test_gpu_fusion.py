@@ -99,13 +99,54 @@ def test_batch_on_two_streams_equals_back_to_back(td, dev):
     make = lambda: bench.build_pipeline(td, dev, w, h, 'f16', 'isp')[1]
     serial = make()
     ref = [serial(b).clone() for b in inputs]
-    runner = FrameStreams(dev, make, streams=2)
-    for _ in range(3):   # repeated: a race would not hit every time
-        outs = runner.run(inputs)          # joined: usable on the current stream
-        for i in range(frames):
-            assert torch.equal(outs[i], ref[i]), f'frame {i} differs between the two-stream and the one-stream run'
+    for nstreams in (2, 3):  # 3 = the bench's setting: the rotation over the streams carries over from batch to batch (6 frames, then 5)
+        runner = FrameStreams(dev, make, streams=nstreams)
+        for rep in range(3):   # repeated: a race would not hit every time
+            batch = inputs if rep != 1 else inputs[:5]
+            outs = runner.run(batch)          # joined: usable on the current stream
+            for i in range(len(batch)):
+                # (the serial reference runs rs::rcd_stream, the streamed frames the register-blocked strips: TDK_RCD_CONCURRENT)
+                assert torch.equal(outs[i], ref[i]), f'frame {i} differs between the {nstreams}-stream and the one-stream run'
     one = FrameStreams(dev, make, streams=1).run(inputs)
     assert all(torch.equal(a, b) for a, b in zip(one, ref))
+
+
+def test_concurrent_frames_context(td, dev):
+    """concurrent_frames() sets TDK_RCD_CONCURRENT for the calling thread only and restores what was there; RCD.process under it
+    gives the bits of the default call (the register-blocked strips against rs::rcd_stream) -- and the library refuses flag bits
+    it does not know."""
+    import ctypes as C
+    import threading
+
+    from torch_darktable import torch_darktable_extension as ext
+    from torch_darktable._native import lib
+    from torch_darktable.synthetic import synthetic_bayer
+
+    seen = {}
+    with ext.concurrent_frames():
+        t = threading.Thread(target=lambda: seen.setdefault('other', getattr(ext._verify, 'concurrent', 0)))
+        t.start()
+        t.join()
+        seen['mine'] = ext._verify.concurrent
+        with ext.concurrent_frames(False):
+            seen['inner'] = ext._verify.concurrent
+        seen['back'] = ext._verify.concurrent
+    assert seen == {'other': 0, 'mine': ext.TDK_RCD_CONCURRENT, 'inner': 0, 'back': ext.TDK_RCD_CONCURRENT}
+    assert getattr(ext._verify, 'concurrent', 0) == 0
+    w, h = 1200, 700
+    for dt in (torch.float32, torch.float16):
+        bayer = synthetic_bayer(h, w, seed=5, device=dev).to(dt)
+        ws = td.RCD(dev, (w, h), td.BayerPattern.GRBG)
+        plain = ws.process(bayer).clone()
+        with ext.concurrent_frames():
+            quad = ws.process(bayer).clone()
+            with ext.verification_paths(rcd_tiles=True):  # both flags at once: the tile kernel wins (it serves any frame)
+                tiles = ws.process(bayer).clone()
+        assert torch.equal(plain, quad) and torch.equal(plain, tiles)
+    out = torch.empty(h, w, 3, device=dev)
+    b32 = synthetic_bayer(h, w, seed=5, device=dev)
+    rc = lib.tdk_rcd_ex(C.c_void_p(b32.data_ptr()), C.c_void_p(out.data_ptr()), None, w, h, C.c_uint32(0x94949494), 0, 4, None)
+    assert rc != 0 and b'unknown flags' in lib.tdk_last_error()
 
 
 def test_metrics_one_launch_equals_two_launches(td, dev):

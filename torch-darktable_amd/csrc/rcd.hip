@@ -743,6 +743,9 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       // segments: as many workgroups as the chip holds at once (3 per CU), but no segment shorter than 64 rows (20 rows of
       // warm-up / drain per segment)
       int nsegs = (3 * tdk_device_cus()) / nstrips;
+#ifdef TDK_EXPERIMENTS
+      if (const char* e = getenv("TDK_RCD_NSEGS")) nsegs = atoi(e);  // fewer, longer segments: less warm-up per row, fewer workgroups than slots
+#endif
       if (nsegs < 1) nsegs = 1;
       if (nsegs > h / 64) nsegs = h / 64;
       int seg_rows = (tdk_div_up(h, nsegs) + 1) & ~1;  // even: segment origins keep the CFA phase
