@@ -17,7 +17,7 @@ tag = sys.argv[1]
 src, dst = Path('gpurun_out') / tag, Path('profiles') / tag
 dst.mkdir(exist_ok=True)
 for name in ['bench_isp_plain.json', 'bench_rcd_plain.json', 'bench_ppg_wiener50_plain.json', 'bench_isp_streams1_plain.json', 'bench_isp_streams2_plain.json', 'bench_isp_under_rocprof.json', 'op_bench_f16.json', 'op_bench_f32.json', 'op_bench_50mp_f16.json',
-             'laplacian_kernels.txt', 'traffic.json']:
+             'laplacian_kernels.txt', 'traffic.json', 'bench_isp_repeats.txt']:
     if (src / name).exists():
         shutil.copy(src / name, dst / name)
 shutil.copy(src / 'stats' / 'bench_kernel_stats.csv', dst / 'bench_isp_kernel_stats.csv')
