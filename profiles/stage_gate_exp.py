@@ -15,6 +15,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--streams', type=int, default=3)
     ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--modes', default='free,rcd,all,heavy,free')
+    ap.add_argument('--sleep', type=float, default=0.0, help='idle seconds before each timed region (after its warm-up steps)')
+    ap.add_argument('--warm', type=int, default=5)
     a = ap.parse_args()
     import torch_darktable as td
     from torch_darktable.synthetic import synthetic_bayer
@@ -32,7 +35,8 @@ def main():
 
     chains = [make() for _ in range(a.streams)]
     streams = [torch.cuda.Stream(dev) for _ in range(a.streams)]
-    for mode in ('free', 'rcd', 'all', 'heavy', 'free'):
+    ap_modes = a.modes.split(',')
+    for mode in ap_modes:
         nxt = [0]
         prev = [None] * 4
 
@@ -58,9 +62,11 @@ def main():
                         x = stage(2, lambda: c['bil'].process_rgb(x, 0.4, luminance=c['lum'], metrics=c['acc']))
                         stage(3, lambda: td.reinhard_tonemap(x, c['acc'].finish(), params))
 
-        for _ in range(5):
+        for _ in range(a.warm):
             step()
         torch.cuda.synchronize()
+        if a.sleep:
+            time.sleep(a.sleep)
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
