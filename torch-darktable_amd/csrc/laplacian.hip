@@ -282,11 +282,20 @@ __global__ __launch_bounds__(256) void reduce_pair_kernel(Layout L, int l) {
   const int fx0 = 2 * clampc(into(ox, w1), w1) - 2, fx1 = 2 * clampc(into(ox + P_WIN - 1, w1), w1) + 2;
   const int fy0 = 2 * clampc(into(oy, h1), h1) - 2, fy1 = 2 * clampc(into(oy + P_WIN - 1, h1), h1) + 2;
   if (fx1 - fx0 == P_FW - 1 && fy1 - fy0 == P_FW - 1) {  // full window: 4 cells per load (the 80th column is read but never used)
-    for (int i = threadIdx.x; i < P_FW * P_FQ; i += 256) {
-      const int r = i / P_FQ, q = i - r * P_FQ;
-      uint2 u;
-      __builtin_memcpy(&u, fine + (size_t)(fy0 + r) * fw + fx0 + 4 * q, 8);
-      *reinterpret_cast<uint2*>(&fwin[r * P_FS + 4 * q]) = u;
+    // all of a thread's loads in flight before the first one is stored (a load -> store loop pays one memory round trip per
+    // round, seven in a row: 69 -> 63 us.  The same change in the assemble kernels' staging and per-pixel loads made THEM 12 %
+    // slower -- more registers, and their waves already overlap each other's round trips; profiles/r04/experiments/laplacian_small_levels.txt)
+    constexpr int NL = (P_FW * P_FQ + 255) / 256;
+    uint2 u[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const int i = threadIdx.x + 256 * k, r = i / P_FQ, q = i - r * P_FQ;
+      if (i < P_FW * P_FQ) __builtin_memcpy(&u[k], fine + (size_t)(fy0 + r) * fw + fx0 + 4 * q, 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const int i = threadIdx.x + 256 * k, r = i / P_FQ, q = i - r * P_FQ;
+      if (i < P_FW * P_FQ) *reinterpret_cast<uint2*>(&fwin[r * P_FS + 4 * q]) = u[k];
     }
   } else {
     for (int i = threadIdx.x; i < P_FW * P_FW; i += 256) {
