@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--modes', default='free,rcd,all,heavy,free')
     ap.add_argument('--sleep', type=float, default=0.0, help='idle seconds before each timed region (after its warm-up steps)')
     ap.add_argument('--warm', type=int, default=5)
+    ap.add_argument('--prio', default='', help='comma list of stream priorities (-1 = high, 0 = normal), e.g. -1,0,0')
     a = ap.parse_args()
     import torch_darktable as td
     from torch_darktable.synthetic import synthetic_bayer
@@ -34,7 +35,9 @@ def main():
                     acc=td.tonemap.MetricsAccumulator(dev, stride=8))
 
     chains = [make() for _ in range(a.streams)]
-    streams = [torch.cuda.Stream(dev) for _ in range(a.streams)]
+    prio = [int(x) for x in a.prio.split(',')] if a.prio else [0] * a.streams
+    streams = [torch.cuda.Stream(dev, priority=prio[k % len(prio)]) for k in range(a.streams)]
+    print('stream priorities', prio, torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else '')
     ap_modes = a.modes.split(',')
     for mode in ap_modes:
         nxt = [0]
