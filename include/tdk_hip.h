@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TDK_ABI_VERSION 2
+#define TDK_ABI_VERSION 3
 
 typedef void* tdk_stream_t; /* hipStream_t */
 
@@ -86,6 +86,13 @@ int tdk_rcd(const void* bayer, void* rgb, void* workspace, int width, int height
  * then run as their register-blocked variant (csrc/tdk_rcd_quad.h): the same bits on half the waves per CU, which is slower
  * with the GPU to itself and faster for the whole when other frames' kernels can use the wave slots and registers it leaves. */
 #define TDK_RCD_CONCURRENT 2u
+/* Arithmetic of a binary16 (TDK_F16) result.  float32 results are always the oracle's bits (its operation order, no
+ * contraction, correctly rounded quotients).  A binary16 result of the column strips is by default computed with the
+ * approximate flavour (csrc/tdk_rcd_stream.h: a * v_rcp_f32(b) quotients, fused sums of products -- the class of arithmetic of
+ * the reference's own nvcc --use_fast_math build, setup.py:36): a few fp32 ulps before the store, i.e. one binary16 ulp on
+ * ~5e-5 of the values against the exact result rounded once, far inside the 2e-3 relative tolerance of fp16 storage, for 23 %
+ * fewer instructions.  TDK_RCD_EXACT asks for the exact flavour rounded once instead (the tile kernel always is). */
+#define TDK_RCD_EXACT 4u
 int tdk_rcd_ex(const void* bayer, void* rgb, void* workspace, int width, int height, uint32_t pattern, int dtype, unsigned flags,
                tdk_stream_t stream);
 
@@ -99,6 +106,9 @@ int tdk_rcd_ex(const void* bayer, void* rgb, void* workspace, int width, int hei
 size_t tdk_decode12_wb_rcd_workspace_bytes(int width, int height);
 int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
                         int ids_format, int out_dtype, tdk_stream_t stream);
+/* The same with the per-call flags of tdk_rcd_ex (TDK_RCD_CONCURRENT, TDK_RCD_EXACT, TDK_RCD_TILE_KERNEL). */
+int tdk_decode12_wb_rcd_ex(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
+                           int ids_format, int out_dtype, unsigned flags, tdk_stream_t stream);
 
 /* PostProcess.process: reference csrc/debayer/postprocess.cu:311-390 (extension.cpp:77-90).
  * in and out must not alias.  The global green ratio is computed and consumed on the

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(td):
     for name in _declared_functions():
         assert hasattr(lib, name), f'{name} declared in tdk_hip.h but not exported'
     lib.tdk_abi_version.restype = ctypes.c_int
-    assert lib.tdk_abi_version() == 2
+    assert lib.tdk_abi_version() == 3
 
 
 def test_ctypes_table_matches_header(td):

@@ -55,6 +55,36 @@ def test_rcd_12mp_crop_consistency_and_native(td, oracle, dev, frame12):
     assert torch.isfinite(out).all()
 
 
+def test_rcd_12mp_fp16_fast_arithmetic(td, oracle, dev, frame12):
+    """BASELINE config 3's demosaic: float16 storage, the approximate arithmetic flavour of the column strips (default for
+    float16 results; csrc/tdk_rcd_stream.h) on the whole 12 MP frame.  Windows against the fp32 oracle rounded to binary16: at
+    most one binary16 ulp except on <= 1e-5 of the pixels (selection flips); the register-blocked strips (what FrameStreams
+    runs) give the same bits on every pixel of the frame; native samples pass through."""
+    from torch_darktable import torch_darktable_extension as ext
+
+    b16 = frame12.half()
+    ws = td.RCD(dev, (W12, H12), td.BayerPattern.RGGB)
+    out = ws.process(b16)
+    with ext.concurrent_frames():
+        quad = ws.process(b16)
+    assert out.dtype == torch.float16 and torch.equal(out, quad)
+    m, n = 16, 256
+    beyond = touched = 0
+    for y0, x0 in WINDOWS + [(8, 8), (H12 - n - 8, W12 - n - 8)]:
+        ref = oracle.rcd(window(b16, y0, x0, n, m)[:, :, :1], oracle.RGGB)[m:-m, m:-m]
+        got = npy(out[y0:y0 + n, x0:x0 + n])
+        r16 = ref.astype(np.float16).astype(np.float32)
+        d = np.abs(got - r16)
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(got), np.abs(r16)), 2.0 ** -14))) - 10)
+        beyond += int((d > ulp).any(-1).sum())
+        touched += int((d > 0).sum())
+    npx = 5 * n * n
+    assert beyond <= 1e-5 * npx + 1 and touched <= 1e-3 * 3 * npx, (beyond, touched, npx)
+    assert torch.equal(out[0::2, 0::2, 0], b16[0::2, 0::2, 0].clamp_min(0))
+    assert torch.equal(out[1::2, 1::2, 2], b16[1::2, 1::2, 0].clamp_min(0))
+    assert torch.isfinite(out).all()
+
+
 def test_rcd_12mp_right_and_bottom_edges(td, oracle, dev, frame12):
     """The stale p/q slots of the reference's shared scratch planes influence the last columns /
     rows; check those against a full-width / full-height strip of the oracle is too costly, so
@@ -77,11 +107,12 @@ def test_rcd_strips_equal_tiles_on_whole_frames(td, dev, shape):
     for pattern in (td.BayerPattern.RGGB, td.BayerPattern.GBRG):
         ws = td.RCD(dev, (w, h), pattern)
         for x in (bayer, bayer.half()):
-            strips = ws.process(x)
+            with ext.verification_paths(rcd_exact=True):  # (float16 results: the exact flavour rounded once, as the tile kernel's)
+                strips = ws.process(x)
+                with ext.concurrent_frames():  # the register-blocked strips (TDK_RCD_CONCURRENT)
+                    quad = ws.process(x)
             with ext.verification_paths(rcd_tiles=True):
                 tiles = ws.process(x)
-            with ext.concurrent_frames():  # the register-blocked strips (TDK_RCD_CONCURRENT)
-                quad = ws.process(x)
             assert torch.equal(strips, tiles), f'{shape} {pattern} {x.dtype}: {(strips != tiles).sum().item()} values differ'
             assert torch.equal(quad, tiles), f'{shape} {pattern} {x.dtype}, register-blocked strips: {(quad != tiles).sum().item()} values differ'
             del strips, tiles, quad
@@ -163,8 +194,12 @@ def test_full_pipeline_12mp_fp16_vs_fp32_oracle(td, oracle, dev, frame12):
     ref_rgb = r[m:-m, m:-m]
     rel = np.abs(got_rgb - ref_rgb) / np.maximum(ref_rgb.max(-1, keepdims=True), 1e-3)
     assert rel.max() < 2e-3, rel.max()
+    # the stricter per-VALUE form of the same tolerance (each channel against itself, floor 0.05: below it the absolute
+    # error of the pixel's brighter channels dominates): measured 1.5e-3 (profiles/r04/fp16_chain_error.json)
+    rel_ch = np.abs(got_rgb - ref_rgb) / np.maximum(np.abs(ref_rgb), 0.05)
+    assert rel_ch.max() < 2e-3, rel_ch.max()
     d = np.abs(npy(u8[y0:y0 + n, x0:x0 + n]).astype(np.int32) - ref_u8.astype(np.int32))
-    assert d.max() <= 2 and (d > 1).mean() < 1e-2
+    assert d.max() <= 2 and (d > 1).mean() <= 1e-5, (d.max(), (d > 1).mean())  # measured: 8e-8 of the values above 1 LSB
 
 
 def test_config5_50mp_ppg_wiener_fp16(td, oracle, dev):

@@ -771,6 +771,22 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
         quad = atoi(e) != 0;
       }
 #endif
+      // binary16 results: the approximate arithmetic flavour of the strips (tdk_rcd_stream.h), unless the caller asks for the
+      // oracle's bits rounded once (TDK_RCD_EXACT)
+      if constexpr (sizeof(T) == 2) {
+        if (!(flags & TDK_RCD_EXACT)) {
+          if (quad) {
+            const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<4, TI, T, true>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+            if (rcq != TDK_OK) return rcq;
+            TDK_LAUNCH("tdk_rcd(concurrent)", (rq::rcd_quad<4, TI, T, true>), dim3((unsigned)nwg), dim3(rq::Geo<4>::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+            return TDK_OK;
+          }
+          const int rca = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rs::rcd_stream<TI, T, true>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
+          if (rca != TDK_OK) return rca;
+          TDK_LAUNCH("tdk_rcd", (rs::rcd_stream<TI, T, true>), dim3((unsigned)nwg), dim3(rs::NT), strip_lds, s, in, out, w, h, pattern, nstrips, seg_rows, nbx, nby);
+          return TDK_OK;
+        }
+      }
       if (quad) {
         const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<4, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");
         if (rcq != TDK_OK) return rcq;
@@ -810,7 +826,7 @@ TDK_EXPORT int tdk_rcd_ex(const void* bayer, void* rgb, void* /*workspace*/, int
   TDK_REQUIRE((width & 1) == 0, "tdk_rcd: width must be even (the reference packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
               "tdk_rcd: invalid Bayer pattern 0x%08x", pattern);
-  TDK_REQUIRE((flags & ~(TDK_RCD_TILE_KERNEL | TDK_RCD_CONCURRENT)) == 0, "tdk_rcd: unknown flags 0x%x", flags);
+  TDK_REQUIRE((flags & ~(TDK_RCD_TILE_KERNEL | TDK_RCD_CONCURRENT | TDK_RCD_EXACT)) == 0, "tdk_rcd: unknown flags 0x%x", flags);
   TDK_DISPATCH_DTYPE(dtype, T, return launch<T>(bayer, rgb, width, height, pattern, flags, tdk_stream(stream)));
   return TDK_OK;
 }
@@ -830,9 +846,10 @@ TDK_EXPORT size_t tdk_decode12_wb_rcd_workspace_bytes(int width, int height) {
   return width > 0 && height > 0 ? tdk_align_up((size_t)width * height * sizeof(float), 256) : 0;
 }
 
-TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
-                                   int ids_format, int out_dtype, tdk_stream_t stream) {
+TDK_EXPORT int tdk_decode12_wb_rcd_ex(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
+                                      int ids_format, int out_dtype, unsigned flags, tdk_stream_t stream) {
   TDK_REQUIRE(packed && rgb && workspace, "tdk_decode12_wb_rcd: null pointer");
+  TDK_REQUIRE((flags & ~(TDK_RCD_TILE_KERNEL | TDK_RCD_CONCURRENT | TDK_RCD_EXACT)) == 0, "tdk_decode12_wb_rcd: unknown flags 0x%x", flags);
   TDK_REQUIRE(width > 0 && height > 0, "tdk_decode12_wb_rcd: invalid size %dx%d", width, height);
   TDK_REQUIRE((width & 1) == 0, "tdk_decode12_wb_rcd: width must be even (pixel pairs share three bytes; RCD packs half-density planes as idx/2)");
   TDK_REQUIRE(pattern == TDK_PATTERN_RGGB || pattern == TDK_PATTERN_BGGR || pattern == TDK_PATTERN_GRBG || pattern == TDK_PATTERN_GBRG,
@@ -840,8 +857,13 @@ TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* works
   float* mosaic = reinterpret_cast<float*>(workspace);
   const int rc = tdk_decode12_wb_plane(packed, mosaic, gains, width, height, pattern, ids_format, tdk_stream(stream));
   if (rc != TDK_OK) return rc;
-  if (out_dtype == TDK_F32) return launch_mixed<float, float>(mosaic, rgb, width, height, pattern, 0u, tdk_stream(stream));
-  if (out_dtype == TDK_F16) return launch_mixed<float, __half>(mosaic, rgb, width, height, pattern, 0u, tdk_stream(stream));
+  if (out_dtype == TDK_F32) return launch_mixed<float, float>(mosaic, rgb, width, height, pattern, flags, tdk_stream(stream));
+  if (out_dtype == TDK_F16) return launch_mixed<float, __half>(mosaic, rgb, width, height, pattern, flags, tdk_stream(stream));
   tdk_set_error("unsupported dtype tag %d", out_dtype);
   return TDK_ERR_INVALID_ARGUMENT;
+}
+
+TDK_EXPORT int tdk_decode12_wb_rcd(const uint8_t* packed, void* rgb, void* workspace, const float* gains, int width, int height, uint32_t pattern,
+                                   int ids_format, int out_dtype, tdk_stream_t stream) {
+  return tdk_decode12_wb_rcd_ex(packed, rgb, workspace, gains, width, height, pattern, ids_format, out_dtype, 0u, stream);
 }

@@ -107,8 +107,8 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
     for (int k = 0; k < CPL / 2; k++) {
       const int ci = p + 2 * k;
       auto a = [&](int dr, int dc) { return tap(c[dr + 1], ci + dc); };
-      const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
-      if constexpr (MODE == INNER) o[k] = v;
+      const float v = lpf9<approx(MODE)>(a(0, 0), a(-1, 0), a(1, 0), a(0, -1), a(0, 1), a(-1, -1), a(-1, 1), a(1, -1), a(1, 1));
+      if constexpr (!has_rules(MODE)) o[k] = v;
       else { const int gy = gyb - L; o[k] = keep(colrow(gy >= 2 && gy <= t.h - 2, t.gxq + ci, 2, t.w - 2), v); }
     }
     stv(t.bH + rowH<LPF_B, LPF_L, LPF_W>(L, 0), o);
@@ -125,9 +125,9 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
 #pragma unroll
     for (int ci = 0; ci < CPL; ci++) {
       auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
-      vd[ci] = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
-      hd[ci] = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
-      if constexpr (MODE != INNER) {
+      vd[ci] = sqf(hp7<approx(MODE)>(a(-3, 0), a(-2, 0), a(-1, 0), a(0, 0), a(1, 0), a(2, 0), a(3, 0)));
+      hd[ci] = sqf(hp7<approx(MODE)>(a(0, -3), a(0, -2), a(0, -1), a(0, 0), a(0, 1), a(0, 2), a(0, 3)));
+      if constexpr (has_rules(MODE)) {
         const lmask ok = colrow(gy >= 3 && gy <= t.h - 4, t.gxq + ci, 3, t.w - 4);
         vd[ci] = keep(ok, vd[ci]);
         hd[ci] = keep(ok, hd[ci]);
@@ -140,9 +140,9 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
     for (int k = 0; k < CPL / 2; k++) {
       const int ci = 1 + 2 * k;
       auto a = [&](int dr, int dc) { return tap(c[dr + 3], ci + dc); };
-      pv[k] = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
-      qv[k] = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
-      if constexpr (MODE != INNER) {
+      pv[k] = sqf(dg7<approx(MODE)>(a(-3, -3), a(-2, -2), a(-1, -1), a(0, 0), a(1, 1), a(2, 2), a(3, 3)));
+      qv[k] = sqf(dg7<approx(MODE)>(a(-3, 3), a(-2, 2), a(-1, 1), a(0, 0), a(1, -1), a(2, -2), a(3, -3)));
+      if constexpr (has_rules(MODE)) {
         // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
         // rcd.hip); outside the frame: 0
         const int gx = t.gxq + ci;
@@ -177,8 +177,8 @@ __device__ __forceinline__ void q_step_1_2_4_2(const Lane& t, int gyb) {
       const float eps = 1e-10f;
       const float V_Stat = fmaxf(eps, vdr[0].v[ci] + vdr[1].v[ci] + vdr[2].v[ci]);
       const float H_Stat = fmaxf(eps, tap(hdr, ci - 1) + tap(hdr, ci) + tap(hdr, ci + 1));
-      vh[ci] = div_pos<MODE != SLOW>(V_Stat, V_Stat + H_Stat);
-      if constexpr (MODE != INNER) vh[ci] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + ci, 2, t.w - 3), vh[ci]);
+      vh[ci] = qdiv<MODE>(V_Stat, V_Stat + H_Stat);
+      if constexpr (has_rules(MODE)) vh[ci] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + ci, 2, t.w - 3), vh[ci]);
     }
     stv(t.bF + rowF<VH_B, VH_L, VH_W>(L, 0), vh);
   }
@@ -198,8 +198,8 @@ __device__ __forceinline__ void q_step_1_2_4_2(const Lane& t, int gyb) {
       const float P_Stat = fmaxf(eps, tap(pr[0], k + jm) + pr[1].v[k] + tap(pr[2], k + jm + 1));
       const float Q_Stat = fmaxf(eps, tap(qr[0], k + jm + 1) + qr[1].v[k] + tap(qr[2], k + jm));
       // plain division wherever a stale slot (see step 4.1) can be near: it holds values of samples no range check has seen
-      pq[k] = div_pos<MODE == INNER>(P_Stat, P_Stat + Q_Stat);
-      if constexpr (MODE != INNER) pq[k] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + p + 2 * k, 2, t.w - 3), pq[k]);
+      pq[k] = qdiv42<MODE>(P_Stat, P_Stat + Q_Stat);
+      if constexpr (has_rules(MODE)) pq[k] = keep(colrow(gy >= 2 && gy <= t.h - 3, t.gxq + p + 2 * k, 2, t.w - 3), pq[k]);
     }
     stv(t.bH + rowH<PQ_B, PQ_L, PQ_W>(L, 0), pq);
   }
@@ -234,14 +234,14 @@ __device__ __forceinline__ void q_step_3_1(const Lane& t, int gyb) {
     const float W_Grad = eps + fabsf(a(0, -1) - a(0, 1)) + fabsf(cfai - a(0, -2)) + fabsf(a(0, -1) - a(0, -3)) + fabsf(a(0, -2) - a(0, -4));
     const float E_Grad = eps + fabsf(a(0, 1) - a(0, -1)) + fabsf(cfai - a(0, 2)) + fabsf(a(0, 1) - a(0, 3)) + fabsf(a(0, 2) - a(0, 4));
     const float lpfi = lp(0, 0);
-    const float N_Est = div_pos<MODE != SLOW>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
-    const float S_Est = div_pos<MODE != SLOW>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
-    const float W_Est = div_pos<MODE != SLOW>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
-    const float E_Est = div_pos<MODE != SLOW>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
-    const float V_Est = div_pos<MODE != SLOW>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
-    const float H_Est = div_pos<MODE != SLOW>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
-    g[k] = mixf(V_Est, H_Est, VH_Disc);
-    if constexpr (MODE != INNER) { const int gy = gyb - L; g[k] = keep(colrow(gy >= 4 && gy <= t.h - 5, t.gxq + ci, 4, t.w - 5), g[k]); }
+    const float N_Est = qdiv<MODE>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
+    const float S_Est = qdiv<MODE>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
+    const float W_Est = qdiv<MODE>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
+    const float E_Est = qdiv<MODE>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
+    const float V_Est = qdiv<MODE>(dot2<approx(MODE)>(S_Grad, N_Est, N_Grad, S_Est), N_Grad + S_Grad);
+    const float H_Est = qdiv<MODE>(dot2<approx(MODE)>(W_Grad, E_Est, E_Grad, W_Est), E_Grad + W_Grad);
+    g[k] = mixq<approx(MODE)>(V_Est, H_Est, VH_Disc);
+    if constexpr (has_rules(MODE)) { const int gy = gyb - L; g[k] = keep(colrow(gy >= 4 && gy <= t.h - 5, t.gxq + ci, 4, t.w - 5), g[k]); }
   }
   stv(t.bH + rowH<GRN_B, GRN_L, GRN_W>(L, 0), g);
 }
@@ -285,13 +285,13 @@ __device__ __forceinline__ void q_step_5_1(const Lane& t, int gyb, lmask rel) {
     const float NE_Est = a(-1, 1) - G(-1, 1);
     const float SW_Est = a(1, -1) - G(1, -1);
     const float SE_Est = a(1, 1) - G(1, 1);
-    num[2 * k] = NW_Grad * SE_Est + SE_Grad * NW_Est;
-    num[2 * k + 1] = NE_Grad * SW_Est + SW_Grad * NE_Est;
+    num[2 * k] = dot2<approx(MODE)>(NW_Grad, SE_Est, SE_Grad, NW_Est);
+    num[2 * k + 1] = dot2<approx(MODE)>(NE_Grad, SW_Est, SW_Grad, NE_Est);
     den[2 * k] = NW_Grad + SE_Grad;
     den[2 * k + 1] = NE_Grad + SW_Grad;
-    if constexpr (MODE == INNER) ok[k] = rel;
+    if constexpr (!has_rules(MODE)) ok[k] = rel;
     else { const int gy = gyb - L; ok[k] = colrow(gy >= 4 && gy <= t.h - 4, t.gxq + ci, 4, t.w - 4); }
-    if constexpr (MODE != SLOW) {
+    if constexpr (MODE == FASTM || MODE == INNER) {
       float r;  // min(|num|) of the site where it counts, 1 elsewhere
       const float m2 = fminf(fabsf(num[2 * k]), fabsf(num[2 * k + 1]));
       const lmask cnt = MODE == INNER ? rel : (ok[k] & rel);
@@ -300,12 +300,17 @@ __device__ __forceinline__ void q_step_5_1(const Lane& t, int gyb, lmask rel) {
     }
   }
   float est[CPL];  // P_Est, Q_Est of the sites
-  div_signed_min<MODE != SLOW>(num, den, est, mn);
+  if constexpr (approx(MODE)) {
+#pragma unroll
+    for (int i = 0; i < CPL; i++) est[i] = div_rcp(num[i], den[i]);
+  } else {
+    div_signed_min<MODE != SLOW>(num, den, est, mn);
+  }
   float o[CPL / 2];
 #pragma unroll
   for (int k = 0; k < CPL / 2; k++) {
-    o[k] = g0v[k] + mixf(est[2 * k], est[2 * k + 1], disc[k]);
-    if constexpr (MODE != INNER) o[k] = keep(ok[k], o[k]);
+    o[k] = g0v[k] + mixq<approx(MODE)>(est[2 * k], est[2 * k + 1], disc[k]);
+    if constexpr (has_rules(MODE)) o[k] = keep(ok[k], o[k]);
   }
   stv(t.bH + rowH<COL_B, COL_L, COL_W>(L, 0), o);
 }
@@ -370,12 +375,12 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
       const float S_Est = cS - gS;
       const float W_Est = cW - gW;
       const float E_Est = cE - gE;
-      num[4 * k + 2 * cc] = N_Grad * S_Est + S_Grad * N_Est;
+      num[4 * k + 2 * cc] = dot2<approx(MODE)>(N_Grad, S_Est, S_Grad, N_Est);
       den[4 * k + 2 * cc] = N_Grad + S_Grad;
-      num[4 * k + 2 * cc + 1] = E_Grad * W_Est + W_Grad * E_Est;
+      num[4 * k + 2 * cc + 1] = dot2<approx(MODE)>(E_Grad, W_Est, W_Grad, E_Est);
       den[4 * k + 2 * cc + 1] = E_Grad + W_Grad;
     }
-    if constexpr (MODE != SLOW) {
+    if constexpr (MODE == FASTM || MODE == INNER) {
       float r;
       const float m4 = fminf(fminf(fabsf(num[4 * k]), fabsf(num[4 * k + 1])), fminf(fabsf(num[4 * k + 2]), fabsf(num[4 * k + 3])));
       asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(r) : "v"(m4), "s"(stm));
@@ -383,13 +388,18 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
     }
   }
   float est[2 * CPL];
-  div_signed_min<MODE != SLOW>(num, den, est, mn);
+  if constexpr (approx(MODE)) {
+#pragma unroll
+    for (int i = 0; i < 2 * CPL; i++) est[i] = div_rcp(num[i], den[i]);
+  } else {
+    div_signed_min<MODE != SLOW>(num, den, est, mn);
+  }
   // pixels of the two column pairs (2 k, 2 k + 1): the R/B pixel (native, green from step 3.1, other colour from step 5.1) and
   // the green pixel
 #pragma unroll
   for (int k = 0; k < CPL / 2; k++) {
     const float g = gsite[k];
-    const float own = fmaxf(g + mixf(est[4 * k], est[4 * k + 1], disc[k]), 0.0f), oth = fmaxf(g + mixf(est[4 * k + 2], est[4 * k + 3], disc[k]), 0.0f);
+    const float own = fmaxf(g + mixq<approx(MODE)>(est[4 * k], est[4 * k + 1], disc[k]), 0.0f), oth = fmaxf(g + mixq<approx(MODE)>(est[4 * k + 2], est[4 * k + 3], disc[k]), 0.0f);
     const float native = fmaxf(c[3].v[p + 2 * k], 0.0f), green = fmaxf(gr[1].v[k], 0.0f), other = fmaxf(cr[3].v[k], 0.0f);
     const float gg = fmaxf(g, 0.0f);
     T* d = dst + 6 * k;
@@ -421,7 +431,7 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
 // Workgroup = one segment of one strip (grid: nstrips * nsegs) as in rs::rcd_stream.  CPL = 4: 256 threads, wave wv, half hf of
 // the wave -> row wv + 4 hf of the step's 8-row block, lane q of the half -> window columns 4 q .. 4 q + 3.  CPL = 2: 512 threads,
 // wave wv -> row wv, lane q -> columns 2 q, 2 q + 1.
-template <int CPL, typename TI, typename T>
+template <int CPL, typename TI, typename T, bool AP = false>
 __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Geo<CPL>::WPE, Geo<CPL>::WPE))) void rcd_quad(
     const TI* __restrict__ in, T* __restrict__ out, int w, int h, uint32_t pattern, int nstrips, int seg_rows, int nbx, int nby) {
   using G = Geo<CPL>;
@@ -517,17 +527,22 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
         rg.add(a[2 * k]); rg.add(a[2 * k + 1]);
       }
       stv(t.bF + rowF<CFA_B, CFA_L, CFA_W>(0, 0), a);
-      const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
-      if (lane == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      if constexpr (!AP) {
+        const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
+        if (lane == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      }
       if (b + 1 < nsteps) prefetch(b + 1);
     }
     wg_barrier();
-    uint32_t all = 1u;
+    bool fast = true;
+    if constexpr (!AP) {
+      uint32_t all = 1u;
 #pragma unroll
-    for (int k = 0; k < NT / 64; k++) all &= verdict[(b & 3) * 8 + k];
-    const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
-    const bool fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
-    ok2 = ok1; ok1 = ok0;
+      for (int k = 0; k < NT / 64; k++) all &= verdict[(b & 3) * 8 + k];
+      const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
+      fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
+      ok2 = ok1; ok1 = ok0;
+    }
     // the rows of every step of this block (lags 1 .. 10 behind rows gy0 + 8 b .. + 7) inside every step's row range
     const bool inner = inner_cols && gy0 + RB * b - LAG_52 >= 4 && gy0 + RB * b + RB - 1 - LAG_21 <= h - 5;
 
@@ -552,9 +567,14 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
     wg_barrier();                                                        \
     q_step_5_2_out<CPL, MODEV, PEV, T>(t, red_row, dst, st, stm);        \
   } while (0)
-    if (fast && inner) { if (pe) RQ_STEP(INNER, 1); else RQ_STEP(INNER, 0); }
-    else if (fast) { if (pe) RQ_STEP(FASTM, 1); else RQ_STEP(FASTM, 0); }
-    else { if (pe) RQ_STEP(SLOW, 1); else RQ_STEP(SLOW, 0); }
+    if constexpr (AP) {
+      if (inner) { if (pe) RQ_STEP(AINNER, 1); else RQ_STEP(AINNER, 0); }
+      else { if (pe) RQ_STEP(ABORD, 1); else RQ_STEP(ABORD, 0); }
+    } else {
+      if (fast && inner) { if (pe) RQ_STEP(INNER, 1); else RQ_STEP(INNER, 0); }
+      else if (fast) { if (pe) RQ_STEP(FASTM, 1); else RQ_STEP(FASTM, 0); }
+      else { if (pe) RQ_STEP(SLOW, 1); else RQ_STEP(SLOW, 0); }
+    }
 #undef RQ_STEP
   }
 }

@@ -127,7 +127,52 @@ __device__ __forceinline__ float keep(lmask m, float v) {
 //          range of the nine steps (columns [gx0, gx0 + 128) inside [4, w - 5], the rows of all lags inside [4, h - 5]) and
 //          therefore also of every stale p/q slot (columns 1, w - 3, w - 1, rows < 3 or > h - 4: step 4.1).  At 12 MP that is
 //          36 of the 38 strips and all but the first / last two blocks of a strip's first / last segment.
-constexpr int SLOW = 0, FASTM = 1, INNER = 2;
+//   ABORD  every border rule, approximate arithmetic (below)  \  fp16 results only (TDK_F16 output without TDK_RCD_EXACT): no
+//   AINNER no border rule, approximate arithmetic               /  range check, no IEEE fallback, one code path per block kind
+constexpr int SLOW = 0, FASTM = 1, INNER = 2, ABORD = 3, AINNER = 4;
+constexpr bool has_rules(int mode) { return mode == SLOW || mode == FASTM || mode == ABORD; }
+constexpr bool approx(int mode) { return mode >= ABORD; }
+
+// ---- the arithmetic of the nine steps in two flavours.
+// EXACT (AP = false): the oracle's operation order, no contraction, correctly rounded quotients -- the same bits as
+// oracle/src/rcd.c, whatever the storage type of the result.
+// APPROXIMATE (AP = true): what a result that is ROUNDED TO BINARY16 at the store can afford, and what the reference itself
+// does -- it is an nvcc --use_fast_math build (setup.py:36: approximate division, contraction).  Quotients are a * v_rcp_f32(b)
+// (1 ulp reciprocal; every denominator of the nine steps is >= 1e-10 by construction, so no range wrapper is needed), sums of
+// products are fused, mix(a, b, t) is a + t (b - a).  Each differs from the exact form by a few fp32 ulps: measured against the
+// oracle on the 12 MP test frames <= 4e-7 absolute before the store, i.e. the binary16 result differs from the oracle's in
+// ~5e-5 of the values, by one binary16 ulp (the fp32 value sat next to a rounding boundary), and no selection flips were seen
+// (tests/test_gpu_parity.py::test_rcd_fp16_fast_arithmetic).  23 % fewer VALU instructions per pixel than the exact flavour.
+template <bool AP> __device__ __forceinline__ float hp7(float m3, float m2, float m1, float c, float p1, float p2, float p3) {
+  if constexpr (AP) return __builtin_fmaf(6.0f, c, __builtin_fmaf(-3.0f, m2 + p2, ((m3 - m1) - p1) + p3));
+  else return m3 - 3.0f * m2 - m1 + 6.0f * c - p1 - 3.0f * p2 + p3;
+}
+template <bool AP> __device__ __forceinline__ float dg7(float m3, float m2, float m1, float c, float p1, float p2, float p3) {
+  if constexpr (AP) return __builtin_fmaf(6.0f, c, __builtin_fmaf(-3.0f, m2 + p2, ((m3 - m1) - p1) + p3));
+  else return (m3 - m1 - p1 + p3) - 3.0f * (m2 + p2) + 6.0f * c;
+}
+template <bool AP> __device__ __forceinline__ float lpf9(float c, float n, float s, float w, float e, float nw, float ne, float sw, float se) {
+  if constexpr (AP) return __builtin_fmaf(0.5f, (n + s) + (w + e), __builtin_fmaf(0.25f, (nw + ne) + (sw + se), c));
+  else return c + 0.5f * (n + s + w + e) + 0.25f * (nw + ne + sw + se);
+}
+template <bool AP> __device__ __forceinline__ float dot2(float a, float b, float c, float d) {
+  if constexpr (AP) return __builtin_fmaf(a, b, c * d);
+  else return a * b + c * d;
+}
+template <bool AP> __device__ __forceinline__ float mixq(float a, float b, float t) {
+  if constexpr (AP) return __builtin_fmaf(t, b - a, a);
+  else return mixf(a, b, t);
+}
+__device__ __forceinline__ float div_rcp(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// quotient of non-negative operands: steps 1.2, 3.1 (and 4.2 through qdiv42: the exact fast division only where no stale slot is near)
+template <int MODE> __device__ __forceinline__ float qdiv(float a, float b) {
+  if constexpr (approx(MODE)) return div_rcp(a, b);
+  else return div_pos<MODE != SLOW>(a, b);
+}
+template <int MODE> __device__ __forceinline__ float qdiv42(float a, float b) {
+  if constexpr (approx(MODE)) return div_rcp(a, b);
+  else return div_pos<MODE == INNER>(a, b);
+}
 
 // One step of one wave.  PE = column parity of the R/B sites in this wave's rows of the EVEN-lag steps (odd-lag steps see the
 // other parity: consecutive rows alternate).  b128 / b64: LDS + w * 128 + l / LDS + w * 64 + l.
@@ -138,8 +183,9 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
   {
     constexpr int L = LAG_21, p = PE ^ (L & 1);
     auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
-    const float v = a(0, 0) + 0.5f * (a(-1, 0) + a(1, 0) + a(0, -1) + a(0, 1)) + 0.25f * (a(-1, -1) + a(-1, 1) + a(1, -1) + a(1, 1));
-    b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = MODE == INNER ? v : keep(rule(rv.r21, cv.c2b[p]), v);
+    const float v = lpf9<approx(MODE)>(a(0, 0), a(-1, 0), a(1, 0), a(0, -1), a(0, 1), a(-1, -1), a(-1, 1), a(1, -1), a(1, 1));
+    if constexpr (has_rules(MODE)) b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = keep(rule(rv.r21, cv.c2b[p]), v);
+    else b64[h64<LPF_B, LPF_L, LPF_W>(L, 0, 0)] = v;
   }
   // ---- step 1.1 (lag 3): v_diff / h_diff at both columns
   {
@@ -147,21 +193,26 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, p, dc)]; };
-      const float vd = sqf(a(-3, 0) - 3.0f * a(-2, 0) - a(-1, 0) + 6.0f * a(0, 0) - a(1, 0) - 3.0f * a(2, 0) + a(3, 0));
-      const float hd = sqf(a(0, -3) - 3.0f * a(0, -2) - a(0, -1) + 6.0f * a(0, 0) - a(0, 1) - 3.0f * a(0, 2) + a(0, 3));
-      const lmask ok = rule(rv.r11, cv.c3[p]);
-      b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = MODE == INNER ? vd : keep(ok, vd);
-      b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = MODE == INNER ? hd : keep(ok, hd);
+      const float vd = sqf(hp7<approx(MODE)>(a(-3, 0), a(-2, 0), a(-1, 0), a(0, 0), a(1, 0), a(2, 0), a(3, 0)));
+      const float hd = sqf(hp7<approx(MODE)>(a(0, -3), a(0, -2), a(0, -1), a(0, 0), a(0, 1), a(0, 2), a(0, 3)));
+      if constexpr (has_rules(MODE)) {
+        const lmask ok = rule(rv.r11, cv.c3[p]);
+        b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = keep(ok, vd);
+        b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = keep(ok, hd);
+      } else {
+        b128[f128<VD_B, VD_L, VD_W>(L, 0, p, 0)] = vd;
+        b128[f128<HD_B, HD_L, HD_W>(L, 0, p, 0)] = hd;
+      }
     }
   }
   // ---- step 4.1 (lag 3): p/q_diff at the odd column
   {
     constexpr int L = LAG_41;
     auto a = [&](int dr, int dc) { return b128[f128<CFA_B, CFA_L, CFA_W>(L, dr, 1, dc)]; };
-    const float pd = sqf((a(-3, -3) - a(-1, -1) - a(1, 1) + a(3, 3)) - 3.0f * (a(-2, -2) + a(2, 2)) + 6.0f * a(0, 0));
-    const float qd = sqf((a(-3, 3) - a(-1, 1) - a(1, -1) + a(3, -3)) - 3.0f * (a(-2, 2) + a(2, -2)) + 6.0f * a(0, 0));
+    const float pd = sqf(dg7<approx(MODE)>(a(-3, -3), a(-2, -2), a(-1, -1), a(0, 0), a(1, 1), a(2, 2), a(3, 3)));
+    const float qd = sqf(dg7<approx(MODE)>(a(-3, 3), a(-2, 2), a(-1, 1), a(0, 0), a(1, -1), a(2, -2), a(3, -3)));
     float pv = pd, qv = qd;
-    if constexpr (MODE != INNER) {
+    if constexpr (has_rules(MODE)) {
       // slots step 4.1 does not write keep the same call's v_diff / h_diff of the shared buffer (rcd.cu:637-652; stale_diff in
       // rcd.hip); outside the frame: 0
       const lmask inside = rule(rv.rimg41, cv.img), stale = inside & ~rule(rv.r11, cv.c3[1]);
@@ -188,8 +239,9 @@ __device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __
       const float eps = 1e-10f;
       const float V_Stat = fmaxf(eps, vd(-1) + vd(0) + vd(1));
       const float H_Stat = fmaxf(eps, hd(-1) + hd(0) + hd(1));
-      const float vh = div_pos<MODE != SLOW>(V_Stat, V_Stat + H_Stat);
-      b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = MODE == INNER ? vh : keep(rule(rv.r12, cv.c2a[p]), vh);
+      const float vh = qdiv<MODE>(V_Stat, V_Stat + H_Stat);
+      if constexpr (has_rules(MODE)) b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = keep(rule(rv.r12, cv.c2a[p]), vh);
+      else b128[f128<VH_B, VH_L, VH_W>(L, 0, p, 0)] = vh;
     }
   }
   // ---- step 4.2 (lag 4): PQ_dir at the R/B site (column 2 l + p).  p/q slot of odd column 2 j + 1 = entry j; the slots of
@@ -202,8 +254,9 @@ __device__ __forceinline__ void step_1_2_4_2(float* __restrict__ b128, float* __
     const float P_Stat = fmaxf(eps, P(-1, jm) + P(0, 0) + P(1, jm + 1));
     const float Q_Stat = fmaxf(eps, Q(-1, jm + 1) + Q(0, 0) + Q(1, jm));
     // plain division wherever a stale slot (see step 4.1) can be near: it holds values of samples no range check has seen
-    const float pq = div_pos<MODE == INNER>(P_Stat, P_Stat + Q_Stat);
-    b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = MODE == INNER ? pq : keep(rule(rv.r12, cv.c2a[p]), pq);
+    const float pq = qdiv42<MODE>(P_Stat, P_Stat + Q_Stat);
+    if constexpr (has_rules(MODE)) b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = keep(rule(rv.r12, cv.c2a[p]), pq);
+    else b64[h64<PQ_B, PQ_L, PQ_W>(L, 0, 0)] = pq;
   }
 }
 
@@ -224,14 +277,15 @@ __device__ __forceinline__ void step_3_1(float* __restrict__ b128, float* __rest
   const float W_Grad = eps + fabsf(a(0, -1) - a(0, 1)) + fabsf(cfai - a(0, -2)) + fabsf(a(0, -1) - a(0, -3)) + fabsf(a(0, -2) - a(0, -4));
   const float E_Grad = eps + fabsf(a(0, 1) - a(0, -1)) + fabsf(cfai - a(0, 2)) + fabsf(a(0, 1) - a(0, 3)) + fabsf(a(0, 2) - a(0, 4));
   const float lpfi = lp(0, 0);
-  const float N_Est = div_pos<MODE != SLOW>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
-  const float S_Est = div_pos<MODE != SLOW>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
-  const float W_Est = div_pos<MODE != SLOW>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
-  const float E_Est = div_pos<MODE != SLOW>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
-  const float V_Est = div_pos<MODE != SLOW>(S_Grad * N_Est + N_Grad * S_Est, N_Grad + S_Grad);
-  const float H_Est = div_pos<MODE != SLOW>(W_Grad * E_Est + E_Grad * W_Est, E_Grad + W_Grad);
-  const float grn = mixf(V_Est, H_Est, VH_Disc);
-  b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = MODE == INNER ? grn : keep(rule(rv.r31, cv.c4a[p]), grn);
+  const float N_Est = qdiv<MODE>(a(-1, 0) * (lpfi + lpfi), eps + lpfi + lp(-2, 0));
+  const float S_Est = qdiv<MODE>(a(1, 0) * (lpfi + lpfi), eps + lpfi + lp(2, 0));
+  const float W_Est = qdiv<MODE>(a(0, -1) * (lpfi + lpfi), eps + lpfi + lp(0, -1));
+  const float E_Est = qdiv<MODE>(a(0, 1) * (lpfi + lpfi), eps + lpfi + lp(0, 1));
+  const float V_Est = qdiv<MODE>(dot2<approx(MODE)>(S_Grad, N_Est, N_Grad, S_Est), N_Grad + S_Grad);
+  const float H_Est = qdiv<MODE>(dot2<approx(MODE)>(W_Grad, E_Est, E_Grad, W_Est), E_Grad + W_Grad);
+  const float grn = mixq<approx(MODE)>(V_Est, H_Est, VH_Disc);
+  if constexpr (has_rules(MODE)) b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = keep(rule(rv.r31, cv.c4a[p]), grn);
+  else b64[h64<GRN_B, GRN_L, GRN_W>(L, 0, 0)] = grn;
 }
 
 // ---- step 5.1 (lag 7): the opposite colour at the R/B site.  `lanes_ok`: lanes whose numerators count in the wave's
@@ -258,13 +312,15 @@ __device__ __forceinline__ void step_5_1(float* __restrict__ b128, float* __rest
   const float NE_Est = a(-1, 1) - G(-1, 1);
   const float SW_Est = a(1, -1) - G(1, -1);
   const float SE_Est = a(1, 1) - G(1, 1);
-  float num[2] = {NW_Grad * SE_Est + SE_Grad * NW_Est, NE_Grad * SW_Est + SW_Grad * NE_Est};
+  float num[2] = {dot2<approx(MODE)>(NW_Grad, SE_Est, SE_Grad, NW_Est), dot2<approx(MODE)>(NE_Grad, SW_Est, SW_Grad, NE_Est)};
   float den[2] = {NW_Grad + SE_Grad, NE_Grad + SW_Grad};
-  const lmask ok = MODE == INNER ? ~0ull : rule(rv.r51, cv.c4b[p]);
+  const lmask ok = has_rules(MODE) ? rule(rv.r51, cv.c4b[p]) : ~0ull;
   float est[2];  // P_Est, Q_Est
-  div_signed<MODE != SLOW>(num, den, est, lanes_ok & ok);
-  const float colv = g0 + mixf(est[0], est[1], PQ_Disc);
-  b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = MODE == INNER ? colv : keep(ok, colv);
+  if constexpr (approx(MODE)) { est[0] = div_rcp(num[0], den[0]); est[1] = div_rcp(num[1], den[1]); }
+  else div_signed<MODE != SLOW>(num, den, est, lanes_ok & ok);
+  const float colv = g0 + mixq<approx(MODE)>(est[0], est[1], PQ_Disc);
+  if constexpr (has_rules(MODE)) b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = keep(ok, colv);
+  else b64[h64<COL_B, COL_L, COL_W>(L, 0, 0)] = colv;
 }
 
 // ---- step 5.2 (lag 10) at the green site of the pair + the two finished pixels of the pair
@@ -311,13 +367,18 @@ __device__ __forceinline__ void step_5_2_out(float* __restrict__ b128, float* __
     const float S_Est = cS - gS;
     const float W_Est = cW - gW;
     const float E_Est = cE - gE;
-    num[2 * ci] = N_Grad * S_Est + S_Grad * N_Est;
+    num[2 * ci] = dot2<approx(MODE)>(N_Grad, S_Est, S_Grad, N_Est);
     den[2 * ci] = N_Grad + S_Grad;
-    num[2 * ci + 1] = E_Grad * W_Est + W_Grad * E_Est;
+    num[2 * ci + 1] = dot2<approx(MODE)>(E_Grad, W_Est, W_Grad, E_Est);
     den[2 * ci + 1] = E_Grad + W_Grad;
   }
-  div_signed<MODE != SLOW>(num, den, est, lanes_ok);
-  const float own = fmaxf(g + mixf(est[0], est[1], VH_Disc), 0.0f), oth = fmaxf(g + mixf(est[2], est[3], VH_Disc), 0.0f);
+  if constexpr (approx(MODE)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) est[i] = div_rcp(num[i], den[i]);
+  } else {
+    div_signed<MODE != SLOW>(num, den, est, lanes_ok);
+  }
+  const float own = fmaxf(g + mixq<approx(MODE)>(est[0], est[1], VH_Disc), 0.0f), oth = fmaxf(g + mixq<approx(MODE)>(est[2], est[3], VH_Disc), 0.0f);
   // the R/B pixel of the pair: native, green from step 3.1, other colour from step 5.1
   const float native = fmaxf(b128[f128<CFA_B, CFA_L, CFA_W>(L, 0, p, 0)], 0.0f), green = fmaxf(grn(0, 0), 0.0f), other = fmaxf(col(0, 0), 0.0f);
   const float gg = fmaxf(g, 0.0f);
@@ -365,7 +426,8 @@ __device__ __forceinline__ void wg_barrier() {  // orders LDS traffic only: the 
 // Workgroup = one segment of one strip (grid: nstrips * nsegs), covering the whole frame; the [0, 7) border ring is staged in
 // pieces (ring_piece in rcd.hip: 30 registers; border_pixel's nine-neighbour form cost this kernel two waves per SIMD).
 // Requires: w even and >= TWS + 2 HALO, base pointer aligned for pair loads (host-checked).
-template <typename TI, typename T>
+// AP: the approximate arithmetic flavour (above) -- fp16 results only.
+template <typename TI, typename T, bool AP = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void rcd_stream(const TI* __restrict__ in, T* __restrict__ out, int w, int h,
                                                                                               uint32_t pattern, int nstrips, int seg_rows, int nbx, int nby) {
   extern __shared__ float lds[];
@@ -453,20 +515,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
       }
       b128[f128<CFA_B, CFA_L, CFA_W>(0, 0, 0, 0)] = a0;
       b128[f128<CFA_B, CFA_L, CFA_W>(0, 0, 1, 0)] = a1;
-      Range rg;
-      rg.add(a0);
-      rg.add(a1);
-      const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
-      if (l == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      if constexpr (!AP) {
+        Range rg;
+        rg.add(a0);
+        rg.add(a1);
+        const bool wave_ok = __builtin_amdgcn_ballot_w64(!rg.ok()) == 0;
+        if (l == 0) verdict[(b & 3) * 8 + wv] = wave_ok ? 1u : 0u;
+      }
       if (b + 1 < nsteps) prefetch(b + 1);
     }
     wg_barrier();
-    uint32_t all = 1u;
+    bool fast = true;
+    if constexpr (!AP) {
+      uint32_t all = 1u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) all &= verdict[(b & 3) * 8 + k];
-    const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
-    const bool fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
-    ok2 = ok1; ok1 = ok0;
+      for (int k = 0; k < 8; k++) all &= verdict[(b & 3) * 8 + k];
+      const bool ok0 = __builtin_amdgcn_readfirstlane(all) != 0;
+      fast = ok0 && ok1 && ok2;  // the 24 newest CFA rows >= the 21 rows any step of this block reads
+      ok2 = ok1; ok1 = ok0;
+    }
     // the rows of every step of this block (lags 1 .. 10 behind rows gy0 + 8 b .. + 7) inside every step's row range
     const bool inner = inner_cols && gy0 + RB * b - LAG_52 >= 4 && gy0 + RB * b + RB - 1 - LAG_21 <= h - 5;
 
@@ -499,9 +566,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     RS_PHASE_BARRIER();                                                                                    \
     step_5_2_out<MODEV, PEV, T>(b128, b64, red_row, dst, cv, rv);                                          \
   } while (0)
-    if (fast && inner) { if (pe) RS_STEP(INNER, 1); else RS_STEP(INNER, 0); }
-    else if (fast) { if (pe) RS_STEP(FASTM, 1); else RS_STEP(FASTM, 0); }
-    else { if (pe) RS_STEP(SLOW, 1); else RS_STEP(SLOW, 0); }
+    if constexpr (AP) {
+      if (inner) { if (pe) RS_STEP(AINNER, 1); else RS_STEP(AINNER, 0); }
+      else { if (pe) RS_STEP(ABORD, 1); else RS_STEP(ABORD, 0); }
+    } else {
+      if (fast && inner) { if (pe) RS_STEP(INNER, 1); else RS_STEP(INNER, 0); }
+      else if (fast) { if (pe) RS_STEP(FASTM, 1); else RS_STEP(FASTM, 0); }
+      else { if (pe) RS_STEP(SLOW, 1); else RS_STEP(SLOW, 0); }
+    }
 #undef RS_STEP
 #undef RS_PHASE_BARRIER
   }

@@ -43,6 +43,7 @@ SIGNATURES = {
   'tdk_rcd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, C.c_uint, c_void_p]),
   'tdk_decode12_wb_rcd_workspace_bytes': (c_size_t, [c_int, c_int]),
   'tdk_decode12_wb_rcd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p]),
+  'tdk_decode12_wb_rcd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, C.c_uint, c_void_p]),
   'tdk_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
   'tdk_postprocess': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_int, c_float, c_void_p]),
   'tdk_apply_white_balance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_void_p]),
@@ -92,8 +93,8 @@ def load() -> C.CDLL:
     fn = getattr(lib, name)  # AttributeError here == ABI mismatch between header and library
     fn.restype = restype
     fn.argtypes = argtypes
-  if lib.tdk_abi_version() != 2:
-    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 2')
+  if lib.tdk_abi_version() != 3:
+    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 3')
   return lib
 
 

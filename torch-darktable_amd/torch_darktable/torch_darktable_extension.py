@@ -54,15 +54,17 @@ class BayerPattern(enum.IntEnum):
 # Two ops have a second kernel path that gives the same bits (RCD: 64 x 64 LDS tiles instead of the column strips; Bilateral:
 # the four-kernel path instead of the LDS tile kernel).  The library selects per call (the `flags` of tdk_rcd_ex /
 # tdk_bilateral_ex); this thread-local context is how the GPU tests ask for the other path.  Nothing is process-global.
-TDK_RCD_TILE_KERNEL, TDK_RCD_CONCURRENT, TDK_BILATERAL_PREPARED, TDK_BILATERAL_GENERAL_PATH = 1, 2, 1, 2
+TDK_RCD_TILE_KERNEL, TDK_RCD_CONCURRENT, TDK_RCD_EXACT, TDK_BILATERAL_PREPARED, TDK_BILATERAL_GENERAL_PATH = 1, 2, 4, 1, 2
 _verify = threading.local()
 
 
 @contextlib.contextmanager
-def verification_paths(rcd_tiles: bool = False, bilateral_general: bool = False):
-  """Inside the context (this thread only) RCD.process takes the tile kernel and / or Bilateral the four-kernel path."""
+def verification_paths(rcd_tiles: bool = False, bilateral_general: bool = False, rcd_exact: bool = False):
+  """Inside the context (this thread only) RCD.process takes the tile kernel and / or Bilateral the four-kernel path.
+  rcd_exact: a float16 result of RCD.process is the exact flavour's result rounded once (TDK_RCD_EXACT) instead of the default
+  approximate arithmetic of the column strips (include/tdk_hip.h); float32 results are always exact."""
   old = (getattr(_verify, 'rcd', 0), getattr(_verify, 'bil', 0))
-  _verify.rcd = TDK_RCD_TILE_KERNEL if rcd_tiles else 0
+  _verify.rcd = (TDK_RCD_TILE_KERNEL if rcd_tiles else 0) | (TDK_RCD_EXACT if rcd_exact else 0)
   _verify.bil = TDK_BILATERAL_GENERAL_PATH if bilateral_general else 0
   try:
     yield
@@ -282,8 +284,8 @@ class RCD(_Workspace):
     out = torch.empty((self._height, self._width, 3), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
       ws = self._workspace(lib.tdk_decode12_wb_rcd_workspace_bytes(self._width, self._height), x.device)
-      check(lib.tdk_decode12_wb_rcd(_ptr(x), _ptr(out), _ptr(ws), _ptr(g), self._width, self._height, self._pattern, int(ids_format), _dtype_tag(out),
-                                    _stream()))
+      check(lib.tdk_decode12_wb_rcd_ex(_ptr(x), _ptr(out), _ptr(ws), _ptr(g), self._width, self._height, self._pattern, int(ids_format), _dtype_tag(out),
+                                       getattr(_verify, 'rcd', 0) | getattr(_verify, 'concurrent', 0), _stream()))
     return out
 
 
