@@ -77,6 +77,8 @@ def parse_args(argv=None):
     ap.add_argument('--storage', choices=['f16', 'f32'], default=None, help='image storage type (default: f32 for rcd, f16 otherwise)')
     ap.add_argument('--frames', type=int, default=None, help='frames per GPU per step (default 8 for isp, 1 for rcd, 4 for ppg_wiener50)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
+    ap.add_argument('--chain', choices=['lab', 'rgb'], default='lab',
+                    help='isp: how the pixel travels from the denoiser to the local-contrast stage: lab = lightness + chroma planes (one colour round trip), rgb = the intermediate RGB image')
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--height', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle run (and with it the parity check)')
@@ -212,8 +214,8 @@ def stages(workload: str, s: int):
     if workload == 'isp':
         return {
             'debayer': (1 * s + 3 * s, ['tdk_rcd', 'tdk_rcd(concurrent)', 'tdk_rcd(border)']),
-            'denoise': (3 * s + 3 * s, ['tdk_compute_luminance', 'tdk_wiener(tiles)', 'tdk_wiener(finish+modify)']),
-            'local_contrast': (3 * s + 3 * s, ['tdk_bilateral(tiles)', 'tdk_bilateral(tables)', 'tdk_bilateral(slice+modify)', 'tdk_bilateral(splat)',
+            'denoise': (3 * s + 3 * s, ['tdk_compute_luminance', 'tdk_compute_luminance(lab)', 'tdk_wiener(tiles)', 'tdk_wiener(finish+modify)', 'tdk_wiener(finish+lab)']),
+            'local_contrast': (3 * s + 3 * s, ['tdk_bilateral(tiles)', 'tdk_bilateral(tables)', 'tdk_bilateral(slice+modify)', 'tdk_bilateral(slice+lab)', 'tdk_bilateral(splat)',
                                                 'tdk_bilateral(blur_xy)', 'tdk_bilateral(blur_z)']),
             'tonemap': (3 * s + 3, ['tdk_image_metrics', 'tdk_image_metrics_accumulate', 'tdk_image_metrics_finish', 'tdk_tonemap']),
         }
@@ -232,7 +234,7 @@ def stage_of(kernel: str, workload: str, s: int):
 
 # Bytes ONE LAUNCH of a kernel has to move per pixel (its own compulsory reads + writes): what the composite floor prices a
 # kernel's HBM time on.
-def launch_bytes_per_px(kernel: str, s: int) -> float | None:
+def launch_bytes_per_px(kernel: str, s: int, chain: str = 'lab') -> float | None:
     table = {
         'tdk_rcd': 1 * s + 3 * s,
         'tdk_rcd(concurrent)': 1 * s + 3 * s,                  # the register-blocked strips (frames in flight on other streams)
@@ -241,7 +243,9 @@ def launch_bytes_per_px(kernel: str, s: int) -> float | None:
         'tdk_wiener(tiles)': 4 + 4,                            # fp32 plane in, the denoised plane's sums out (fp32 slabs)
         'tdk_wiener(finish+modify)': 4 + 3 * s + 3 * s + 4,    # sums in, RGB in, RGB out, fp32 lightness of the result out
         'tdk_wiener(finish)': 4 + 1 * s,
-        'tdk_bilateral(tiles)': 4 + 3 * s + 3 * s,             # fp32 lightness in, RGB in, RGB out
+        'tdk_compute_luminance(lab)': 3 * s + 4 + 8,           # Lab hand-over chain: RGB in, fp32 log-lightness and fp32 (a, b) planes out
+        'tdk_wiener(finish+lab)': 4 + 8 + 4,                   # sums in, (a, b) in, fp32 lightness of the result out
+        'tdk_bilateral(tiles)': (4 + 8 + 3 * s) if chain == 'lab' else (4 + 3 * s + 3 * s),  # fp32 lightness in, (a, b) or RGB in, RGB out
         'tdk_tonemap': 3 * s + 3,
         'tdk_image_metrics': 3 * s / 64.0,                     # stride-8 sample grid (one launch: sums + finish by the last workgroup)
         'tdk_image_metrics_accumulate': 3 * s / 64.0,
@@ -265,7 +269,7 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def build_pipeline(td, dev, w, h, storage, workload):
+def build_pipeline(td, dev, w, h, storage, workload, chain='lab'):
     import torch
 
     dtype = torch.float16 if storage == 'f16' else torch.float32
@@ -287,13 +291,25 @@ def build_pipeline(td, dev, w, h, storage, workload):
     lum = torch.empty((h, w), dtype=torch.float32, device=dev)
     acc = td.tonemap.MetricsAccumulator(dev, stride=8)
 
-    def frame(bayer):
+    def frame_two_stage(bayer):  # --chain rgb: the intermediate RGB image between denoiser and local contrast is materialised
         rgb = rcd.process(bayer)
         rgb = wiener.process_log_luminance(rgb, 0.075, luminance_out=lum)
         rgb = bilateral.process_rgb(rgb, 0.4, luminance=lum, metrics=acc)
         return td.reinhard_tonemap(rgb, acc.finish(), params)
 
-    return dtype, frame
+    # Lab hand-over (include/tdk_hip.h: tdk_wiener_log_luminance_lab / tdk_bilateral_lab): the two stages are two Lab round
+    # trips of the same pixel in the reference (denoise.py:54-58, local_contrast.py:109-114); between them the pixel travels as
+    # fp32 lightness plane + fp32 (a, b) plane and is converted back to RGB once.  Same results within the colour operators'
+    # tolerance (tests/test_gpu_lab_chain.py), 34 transcendentals per pixel fewer.
+    ab = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+
+    def frame(bayer):
+        rgb = rcd.process(bayer)
+        wiener.process_log_luminance_lab(rgb, 0.075, luminance_out=lum, chroma_out=ab)
+        rgb = bilateral.process_lab(lum, ab, 0.4, out_dtype=dtype, metrics=acc)
+        return td.reinhard_tonemap(rgb, acc.finish(), params)
+
+    return dtype, (frame_two_stage if chain == 'rgb' else frame)
 
 
 def cpu_baseline(workload, threads, frame0, budget_s=25.0):
@@ -453,8 +469,8 @@ def main(argv=None):
     nstreams = max(1, min(args.streams, frames))
     from torch_darktable.sharding import FrameStreams
 
-    dtype, process = build_pipeline(td, dev, w, h, storage, args.workload)
-    runner = FrameStreams(dev, lambda: build_pipeline(td, dev, w, h, storage, args.workload)[1], streams=nstreams)
+    dtype, process = build_pipeline(td, dev, w, h, storage, args.workload, args.chain)
+    runner = FrameStreams(dev, lambda: build_pipeline(td, dev, w, h, storage, args.workload, args.chain)[1], streams=nstreams)
 
     # device-resident synthetic inputs, per-frame seeds 1234 + i (distinct per rank)
     inputs = [synthetic_bayer(h, w, seed=1234 + rank * frames + i, device=dev).to(dtype) for i in range(frames)]
@@ -531,7 +547,7 @@ def main(argv=None):
         planes = 3 if (args.workload == 'ppg_wiener50' and dom.startswith('tdk_wiener')) else 1  # C = 3: one launch covers the three planes
         alg_bytes = stage_bpp * w * h if stage_bpp else None
         achieved = alg_bytes / avg_s / 1e9 if alg_bytes else None
-        lbpp = launch_bytes_per_px(dom, sbytes)
+        lbpp = launch_bytes_per_px(dom, sbytes, args.chain)
         stage_kernels = stages(args.workload, sbytes)[stage][1] if stage else []
         stage_us = sum(table[k][1] / frames * 1e3 for k in stage_kernels if k in table)  # per frame, GPU to itself
         captured, valu, composite, why_not = None, None, None, None
@@ -571,7 +587,7 @@ def main(argv=None):
             # composite floor of the whole frame: every kernel at the larger of its HBM time and its issue floor
             comp_us, comp_m_us, parts = 0.0, 0.0, {}
             for k, (c, ms_k) in table.items():
-                kb = launch_bytes_per_px(k, sbytes)
+                kb = launch_bytes_per_px(k, sbytes, args.chain)
                 t_hbm = (kb * w * h / (HBM_PEAK_GBS * 1e9)) if kb else 0.0
                 t_alu, t_alu_m = alu_floor_s(k) or 0.0, alu_floor_s(k, **measured) or 0.0
                 parts[k] = {'hbm_us': round(t_hbm * 1e6, 1), 'alu_floor_us': round(t_alu * 1e6, 1), 'alu_floor_measured_us': round(t_alu_m * 1e6, 1),

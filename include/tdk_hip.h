@@ -244,6 +244,23 @@ int tdk_bilateral_rgb_ex(const void* rgb_in, const float* lum_in, void* rgb_out,
 int tdk_bilateral_rgb_lum(const void* rgb_in, const float* lum_in, void* rgb_out, void* workspace, int width, int height, float sigma_s,
                           float sigma_r, float detail, int log_mode, float eps, int dtype, tdk_stream_t stream);
 
+/* ---- Lab hand-over: Wiener.process_log_luminance -> Bilateral.process_rgb as ONE colour round trip.
+ * Both stages of the reference convert the RGB pixel to Lab, replace L and convert back (torch_darktable/denoise.py:54-58,
+ * local_contrast.py:109-114, csrc/device_conversions.h:213-225); between them only L changes.  These entry points carry the
+ * pixel as fp32 lightness plane (H, W) + fp32 chroma plane (H, W, 2) = (a, b) instead of materialising the intermediate RGB
+ * image: tdk_wiener_log_luminance_lab leaves compute_luminance(denoised) in lum_out and the denoised pixels' (a, b) in ab_out
+ * (the pixels the reference's clip to [0, 1] changes are re-derived from the clipped pixel), tdk_bilateral_lab filters lum_in and
+ * writes modify_luminance's result as RGB.  13 + 1 + 6 transcendentals per pixel instead of 9 + 27 + 18; the same result as the
+ * two-stage chain up to the rounding of the skipped sRGB encode / decode round trip (tolerance of the colour operators, 2e-5;
+ * one binary16 rounding fewer for float16 images).  Helper: tdk_compute_log_luminance_lab = compute_log_luminance(rgb, eps) +
+ * the (a, b) of rgb_to_lab(rgb) in one pass.  workspace of the Wiener call: tdk_wiener_log_luminance_workspace_bytes; of the
+ * bilateral call: tdk_bilateral_workspace_bytes (tdk_bilateral_prepare + TDK_BILATERAL_PREPARED as above). */
+int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, int rgb_dtype, tdk_stream_t stream);
+int tdk_wiener_log_luminance_lab(const void* rgb_in, void* workspace, int width, int height, int tile_size, int overlap_factor, const float* sigma,
+                                 float eps, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream);
+int tdk_bilateral_lab(const float* lum_in, const float* ab_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
+                      float detail, int out_dtype, unsigned flags, tdk_stream_t stream);
+
 /* ---- Laplacian.process: reference csrc/local_contrast/laplacian.cu:433-480 (extension.cpp:94-108).
  * num_gamma must be 6 (laplacian.cu:625-634). */
 size_t tdk_laplacian_workspace_bytes(int width, int height, int num_gamma);

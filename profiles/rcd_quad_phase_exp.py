@@ -1,0 +1,38 @@
+"""Experiment: where a step of the register-blocked RCD strips (rq::rcd_quad) spends its time.
+    python profiles/build_variant.py rcd variants/rcd_timing.so -DTDK_EXPERIMENTS -DTDK_RCD_TIMING=1
+    python profiles/rcd_quad_phase_exp.py variants/rcd_timing.so
+Clock deltas of wave 0 of workgroup 300 (mid-frame: INNER blocks), per phase, summed over its 22 steps: entry k = phase k up to
+the barrier that closes it INCLUDING the wait, entry 8 + k = up to the arrival at that barrier (see RQ_MARK in tdk_rcd_quad.h)."""
+import ctypes as C
+import json
+import sys
+
+
+def main(path):
+    import torch
+    lib = C.CDLL(path)
+    lib.tdk_rcd_ex.restype = C.c_int
+    lib.tdk_rcd_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint, C.c_void_p]
+    dev = torch.device('cuda', 0)
+    w, h = 4096, 3072
+    g = torch.Generator(device=dev).manual_seed(1)
+    x32 = torch.rand(h, w, generator=g, device=dev) * 0.9 + 0.05
+    for name, dt, tag, flags in (('f16 approximate quad', torch.float16, 1, 2), ('f16 exact quad', torch.float16, 1, 2 | 4), ('f32 quad', torch.float32, 0, 2)):
+        x = x32.to(dt)
+        y = torch.empty(h, w, 3, dtype=dt, device=dev)
+        run = lambda: lib.tdk_rcd_ex(x.data_ptr(), y.data_ptr(), None, w, h, 0x94949494, tag, flags, None)
+        for _ in range(3):
+            assert run() == 0
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 16)()
+        lib.tdk_debug_rcd_phase_cycles(buf, 1)
+        run()
+        torch.cuda.synchronize()
+        lib.tdk_debug_rcd_phase_cycles(buf, 1)
+        per_step = [round(buf[k] / 22) for k in range(16)]
+        print(json.dumps({'case': name, 'cycles_per_step_incl_wait': per_step[:6], 'sum': sum(per_step[:6]),
+                          'cycles_to_barrier_arrival': per_step[9:13]}))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

@@ -21,8 +21,8 @@ ALLOWED_EXTRA_ARGS = {
 # extra methods / functions: fused entry points and hand-overs; not part of the reference surface
 ALLOWED_EXTRA_METHODS = {
   'RCD': {'process_packed12'},                         # decode12 -> white balance -> RCD as one call
-  'Wiener': {'process_log_luminance'},                 # denoise.py:54-58 as one call
-  'Bilateral': {'process_rgb', 'process_log_rgb', 'grid_size'},  # local_contrast.py:109-125 as one call; grid dimensions
+  'Wiener': {'process_log_luminance', 'process_log_luminance_lab'},  # denoise.py:54-58 as one call; its Lab hand-over form
+  'Bilateral': {'process_rgb', 'process_log_rgb', 'grid_size', 'process_lab'},  # local_contrast.py:109-125 as one call; grid dimensions; Lab hand-over
 }
 # extra module-level names: the metrics accumulator, the pipeline's normalise kernel, the reference's own create_wiener
 # helper (denoise.py:112) and the exception type the reference registers

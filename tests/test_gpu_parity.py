@@ -323,9 +323,20 @@ def test_rcd_fp16_extremes_stay_on_the_exact_path(td, oracle, dev, scene):
     assert same.all(), f'{(~same).sum()} mismatches, first at {np.argwhere(~same)[:5].tolist()}'
     # the default (approximate) flavour has no range wrapper to fall back on: the same extremes must stay finite where the
     # oracle is and within one binary16 ulp of it
+    # -- away from the 65504 block within one binary16 ulp as everywhere; next to it (samples 2e5 times their neighbours) the
+    # sums of products cancel sixteen orders of magnitude and both flavours carry rounding noise of ~1e-7 of the LARGEST
+    # neighbour: there the bound is one binary16 ulp + 2e-7 * (largest sample within 4 pixels)
     with np.errstate(all='ignore'):
         fast = npy(td.RCD(dev, (w, h), td.BayerPattern.RGGB).process(gpu(b16, dev)))
-        assert_f16_close(fast, ref32, 'extremes', flips=2e-4)
+    assert np.isfinite(fast[np.isfinite(ref32)]).all()
+    from scipy.ndimage import maximum_filter
+    near = maximum_filter(b16[:, :, 0].astype(np.float32), size=9)[:, :, None]
+    g, r = fast.astype(np.float32), ref.astype(np.float32)
+    ok = np.isfinite(r)
+    d = np.where(ok, np.abs(g - r), 0.0)
+    tol = half_ulp(np.maximum(np.abs(g), np.where(ok, np.abs(r), 0.0))) + np.where(near > 100.0, 2e-7 * near, 0.0)
+    over = (d > tol).any(-1)
+    assert over.mean() <= 1e-5, f'{over.sum()} pixels beyond the bound, first at {np.argwhere(over)[:5].tolist()}, max |d| {d.max()}'
 
 
 def test_rcd_rejects_odd_width_and_wrong_shape(td, dev):

@@ -27,6 +27,8 @@ ALLOWED_EXTRA_ARGS = {
 # names this repo adds to a module or class
 ALLOWED_EXTRA_NAMES = {
     'debayer': {'RCD.process_packed', 'RCD.process_packed12'},
+    'denoise': {'Wiener.process_log_luminance_lab'},
+    'local_contrast': {'Bilateral.process_lab'},
     'tonemap': {'MetricsAccumulator', 'compute_image_metrics_into'},
 }
 

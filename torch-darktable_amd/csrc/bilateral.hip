@@ -258,6 +258,27 @@ __global__ __launch_bounds__(256) void slice_modify_kernel(const float* __restri
   }
 }
 
+// The same for the Lab hand-over chain: (L, a, b) in, RGB out (MODE 3 of the tile kernel below; this one serves large sigma_s).
+template <typename T>
+__global__ __launch_bounds__(256) void slice_lab_kernel(const float* __restrict__ lum, const float* __restrict__ grid, const float* __restrict__ ab,
+                                                        T* __restrict__ out, int width, int height, GridDims d, float sigma_s, float sigma_r, float detail) {
+  const int64_t n = (int64_t)width * height;
+  const float norm = -detail * sigma_r * 4.0f;
+  const size_t oy = d.sx, oz = (size_t)d.sx * d.sy;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / width), x = (int)(i - (int64_t)y * width);
+    const float L = lum[i];
+    const Sample s = make_sample(x, y, L, d, sigma_s, sigma_r);
+    const float ax = 1.0f - s.fx, ay = 1.0f - s.fy, az = 1.0f - s.fz, bx = s.fx, by = s.fy, bz = s.fz;
+    const float* g = grid + s.ix + oy * s.iy + oz * s.iz;
+    const float Ldiff = g[0] * ax * ay * az + g[1] * bx * ay * az + g[oy] * ax * by * az + g[oy + 1] * bx * by * az + g[oz] * ax * ay * bz +
+                        g[oz + 1] * bx * ay * bz + g[oz + oy] * ax * by * bz + g[oz + oy + 1] * bx * by * bz;
+    const float Lnew = fmaxf(0.0f, L + norm * Ldiff);
+    const f3 r = clip3(cA::lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, Lnew)), ab[2 * i], ab[2 * i + 1])));
+    st(out, (size_t)i * 3, r.x); st(out, (size_t)i * 3 + 1, r.y); st(out, (size_t)i * 3 + 2, r.z);
+  }
+}
+
 // ---- the whole op in one tile kernel (small sigma_s) -------------------------------------------
 // For small sigma_s the grid is as large as the image (12 MP, sigma_s 2, sigma_r 0.2: 2049 x 1537 x 6
 // floats = 76 MB) and the four-kernel path moves it through HBM five times.  Here one workgroup owns
@@ -444,7 +465,9 @@ __device__ __forceinline__ void sample_gz(const float (&v)[N], float (&g)[N], fl
   }
 }
 
-// MODE 0: luminance plane in (TL == T) -> filtered plane out; 1 / 2: fp32 plane + RGB in -> RGB out (linear / log)
+// MODE 0: luminance plane in (TL == T) -> filtered plane out; 1 / 2: fp32 plane + RGB in -> RGB out (linear / log);
+// 3: fp32 plane + the pixels' Lab chroma (a, b: two floats per pixel, passed through the `rgb` pointer) in -> RGB out: the Lab
+// hand-over chain (color.hip: lum_lab_extract) -- modify_luminance without its RGB -> Lab half
 template <typename TL, typename T, int MODE, int VEC>
 #ifndef TDK_BIL_WPE
 #define TDK_BIL_WPE 8  // waves per SIMD the register budget is set for (experiments: co-residency with other frames' kernels)
@@ -662,13 +685,20 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(TDK_BIL_WPE
     const int py = g / GW, y = y0 + py, x = x0 + (g - py * GW) * VEC;
     if (x >= width || y >= height) continue;
     const size_t i0 = (size_t)y * width + x;
-    float Lv[VEC], o[MODE == 0 ? VEC : 3 * VEC];
+    float Lv[VEC], o[MODE == 0 ? VEC : 3 * VEC], c2[MODE == 3 ? 2 * VEC : 1];
     if constexpr (VEC == 4) {
       s4_io<TL>::load(lum, i0 >> 2, Lv);
-      if constexpr (MODE != 0) rgb4_io<T>::load(rgb, i0 >> 2, o);
+      if constexpr (MODE == 3) {
+        const float* ab = reinterpret_cast<const float*>(rgb);
+        s4_io<float>::load(ab, i0 >> 1, c2);
+        s4_io<float>::load(ab, (i0 >> 1) + 1, c2 + 4);
+      } else if constexpr (MODE != 0) {
+        rgb4_io<T>::load(rgb, i0 >> 2, o);
+      }
     } else {
       Lv[0] = ld(lum, i0);
-      if constexpr (MODE != 0) { o[0] = ld(rgb, i0 * 3); o[1] = ld(rgb, i0 * 3 + 1); o[2] = ld(rgb, i0 * 3 + 2); }
+      if constexpr (MODE == 3) { const float* ab = reinterpret_cast<const float*>(rgb); c2[0] = ab[2 * i0]; c2[1] = ab[2 * i0 + 1]; }
+      else if constexpr (MODE != 0) { o[0] = ld(rgb, i0 * 3); o[1] = ld(rgb, i0 * 3 + 1); o[2] = ld(rgb, i0 * 3 + 2); }
     }
     const float gy = gys[y - py_lo];
     const int iy = min((int)gy, d.sy - 2);
@@ -692,6 +722,9 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(TDK_BIL_WPE
       const float Lnew = fmaxf(0.0f, Lp + norm * Ldiff);
       if constexpr (MODE == 0) {
         o[k] = Lnew;
+      } else if constexpr (MODE == 3) {
+        const f3 r = clip3(cA::lab_to_rgb(mk3(fmaxf(0.0f, fminf(1.0f, Lnew)), c2[2 * k], c2[2 * k + 1])));  // the second half of modify_luminance
+        o[3 * k] = r.x; o[3 * k + 1] = r.y; o[3 * k + 2] = r.z;
       } else {
         const f3 c = mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]);
         const f3 r = (MODE == 2) ? cA::modify_log_luminance(c, Lnew) : cA::modify_luminance(c, Lnew);
@@ -886,7 +919,39 @@ int launch_rgb(const void* rgb_in, void* rgb_out, void* workspace, int width, in
   return TDK_OK;
 }
 
+template <typename T>
+int launch_lab(const float* lum, const float* ab, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r, float detail, unsigned flags,
+               hipStream_t s) {
+  const GridDims d = compute_grid_size(width, height, sigma_s, sigma_r);
+  const size_t tables = tile_table_bytes(width, height, sigma_s, sigma_r);
+  int* tab = reinterpret_cast<int*>(workspace);
+  float* grid = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tables);
+  float* tmp = grid + grid_floats(d);
+  TileLds L;
+  size_t lds_bytes = 0;
+  if (!(flags & TDK_BILATERAL_GENERAL_PATH) && plan_tiles(width, height, d, sigma_s, sigma_r, detail, &L, &lds_bytes)) {
+    const bool vec = (width % 4) == 0 && tdk_aligned(rgb_out, 16) && tdk_aligned(lum, 16) && tdk_aligned(ab, 16);
+    return launch_tiles<float, T, 3>(lum, reinterpret_cast<const T*>(ab), reinterpret_cast<T*>(rgb_out), tab, width, height, d, sigma_s, sigma_r, detail, L, lds_bytes,
+                                     vec, (flags & TDK_BILATERAL_PREPARED) != 0, s);
+  }
+  const int rc = build_grid<float>(lum, grid, tmp, width, height, d, sigma_s, sigma_r, s);
+  if (rc != TDK_OK) return rc;
+  TDK_LAUNCH("tdk_bilateral(slice+lab)", slice_lab_kernel<T>, dim3(stream_blocks((int64_t)width * height)), dim3(256), 0, s, lum, grid, ab, reinterpret_cast<T*>(rgb_out),
+             width, height, d, sigma_s, sigma_r, detail);
+  return TDK_OK;
+}
+
 }  // namespace
+
+TDK_EXPORT int tdk_bilateral_lab(const float* lum_in, const float* ab_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
+                                 float detail, int out_dtype, unsigned flags, tdk_stream_t stream) {
+  TDK_REQUIRE(lum_in && ab_in && rgb_out && workspace, "tdk_bilateral_lab: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "Invalid dimensions");
+  TDK_REQUIRE(sigma_s > 0.0f && sigma_r > 0.0f, "tdk_bilateral_lab: sigmas must be positive");
+  TDK_REQUIRE((flags & ~(TDK_BILATERAL_PREPARED | TDK_BILATERAL_GENERAL_PATH)) == 0, "tdk_bilateral_lab: unknown flags 0x%x", flags);
+  TDK_DISPATCH_DTYPE(out_dtype, T, return launch_lab<T>(lum_in, ab_in, rgb_out, workspace, width, height, sigma_s, sigma_r, detail, flags, tdk_stream(stream)));
+  return TDK_OK;
+}
 
 TDK_EXPORT int tdk_bilateral_grid_size(int width, int height, float sigma_s, float sigma_r, int size_xyz[3]) {
   TDK_REQUIRE(width > 0 && height > 0 && sigma_r > 0.0f && size_xyz, "tdk_bilateral_grid_size: invalid arguments");

@@ -102,6 +102,47 @@ __global__ __launch_bounds__(256) void lum_extract_tail(const TR* __restrict__ r
   }
 }
 
+// ---- Lab hand-over of the fused chain Wiener.process_log_luminance -> Bilateral.process_rgb (torch_darktable/denoise.py:54-58,
+// local_contrast.py:109-114 in the reference).  The two stages each convert the RGB pixel to Lab, replace L and convert back
+// (device_conversions.h:213-225); between them only L changes, so the chain can carry the pixel as (L, a, b): this kernel
+// emits the log-lightness plane the denoiser works on AND the pixel's Lab chroma (a, b), the denoiser's finish kernel
+// (wiener.hip: wiener_finish_lab) turns the denoised log-lightness into the lightness of its result (re-deriving L, a, b only
+// for the pixels the reference's clip to [0, 1] changes), and the bilateral epilogue converts (L'', a, b) to RGB once.
+// Per pixel 13 + 1 + 6 transcendentals instead of 9 + 27 + 18.  Same values as the two-stage chain up to the rounding of the
+// skipped sRGB encode -> (store) -> decode round trip: parity by the colour operators' tolerance (2e-5), not bit for bit.
+template <typename TR, int VEC>
+__global__ __launch_bounds__(256) void lum_lab_extract(const TR* __restrict__ rgb, float* __restrict__ loglum, float* __restrict__ ab, int64_t first,
+                                                       int64_t ngroups, float eps) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    float v[3 * VEC], l[VEC], c2[2 * VEC];
+    if constexpr (VEC == 4) rgb4_io<TR>::load(rgb, g, v);
+    else { v[0] = ld(rgb, 3 * (first + g)); v[1] = ld(rgb, 3 * (first + g) + 1); v[2] = ld(rgb, 3 * (first + g) + 2); }
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const f3 c = mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+      const f3 lab = cA::rgb_to_lab(c);  // of the pixel as it is (modify_log_luminance does not clip its input)
+      l[k] = fmaxf(0.0f, lab.x);         // == rgb_to_lab_l(clip3(c)) when no channel leaves [0, 1]: the same Y, the same lab_f
+      c2[2 * k] = lab.y; c2[2 * k + 1] = lab.z;
+      outside = outside || !(c.x >= 0.0f && c.x <= 1.0f && c.y >= 0.0f && c.y <= 1.0f && c.z >= 0.0f && c.z <= 1.0f);
+    }
+    if (__builtin_amdgcn_ballot_w64(outside) != 0) {  // compute_log_luminance clips the pixel first (device_conversions.h:197-207)
+#pragma unroll
+      for (int k = 0; k < VEC; k++) l[k] = cA::rgb_to_lab_l(clip3(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2])));
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) l[k] = tdk_log(fmaxf(eps, l[k]));
+    if constexpr (VEC == 4) {
+      s4_io<float>::store(loglum, g, l);
+      s4_io<float>::store(ab, 2 * g, c2);
+      s4_io<float>::store(ab, 2 * g + 1, c2 + 4);
+    } else {
+      loglum[first + g] = l[0];
+      ab[2 * (first + g)] = c2[0]; ab[2 * (first + g) + 1] = c2[1];
+    }
+  }
+}
+
 // ---- luminance replace
 template <typename TR, typename TL, bool LOG>
 __global__ __launch_bounds__(256) void lum_modify_vec4(const TR* __restrict__ rgb, const TL* __restrict__ lum, TR* __restrict__ out, int64_t ngroups) {
@@ -220,6 +261,25 @@ TDK_EXPORT int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, i
   TDK_REQUIRE(rgb && lum, "tdk_compute_luminance: null pointer");
   TDK_REQUIRE(!log_mode || eps > 0.0f, "Epsilon must be positive");
   TDK_LUM_DISPATCH(run_extract, rgb, lum, npix, eps, tdk_stream(stream));
+}
+
+TDK_EXPORT int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, int rgb_dtype, tdk_stream_t stream) {
+  TDK_REQUIRE(npix >= 0, "tdk_compute_log_luminance_lab: negative pixel count");
+  if (npix == 0) return TDK_OK;
+  TDK_REQUIRE(rgb && loglum && ab, "tdk_compute_log_luminance_lab: null pointer");
+  TDK_REQUIRE(eps > 0.0f, "Epsilon must be positive");
+  hipStream_t s = tdk_stream(stream);
+  TDK_DISPATCH_DTYPE(rgb_dtype, T, {
+    const T* in = reinterpret_cast<const T*>(rgb);
+    int64_t done = 0;
+    if (tdk_aligned(rgb, 16) && tdk_aligned(loglum, 16) && tdk_aligned(ab, 16) && npix >= 4) {
+      const int64_t ng = npix / 4;
+      TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 4>), dim3(stream_grid(ng)), dim3(256), 0, s, in, loglum, ab, (int64_t)0, ng, eps);
+      done = ng * 4;
+    }
+    if (done < npix) TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 1>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, loglum, ab, done, npix - done, eps);
+  });
+  return TDK_OK;
 }
 
 TDK_EXPORT int tdk_modify_luminance(const void* rgb, const void* lum, void* rgb_out, int64_t npix, int log_mode, int rgb_dtype,

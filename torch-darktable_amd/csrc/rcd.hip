@@ -742,7 +742,7 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       const int nstrips = tdk_div_up(w, rs::TWS);
       // segments: as many workgroups as the chip holds at once (3 per CU), but no segment shorter than 64 rows (20 rows of
       // warm-up / drain per segment)
-      int nsegs = (3 * tdk_device_cus()) / nstrips;
+      int nsegs = (rs::WG_PER_CU * tdk_device_cus()) / nstrips;
 #ifdef TDK_EXPERIMENTS
       if (const char* e = getenv("TDK_RCD_NSEGS")) nsegs = atoi(e);  // fewer, longer segments: less warm-up per row, fewer workgroups than slots
 #endif
@@ -760,7 +760,10 @@ int launch_mixed(const void* bayer, void* rgb, int w, int h, uint32_t pattern, u
       if (const char* e = getenv("TDK_RCD_LDS_PAD")) strip_lds += (size_t)atoi(e);  // fewer resident workgroups per CU (occupancy experiment)
 #endif
       bool quad = (flags & TDK_RCD_CONCURRENT) != 0;
-#ifdef TDK_EXPERIMENTS
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RS_RB)
+      quad = true;
+#endif
+#if defined(TDK_EXPERIMENTS) && !defined(TDK_RS_RB)
       if (const char* e = getenv("TDK_RCD_QUAD")) {  // columns per lane of the register-tap variant: 2, else 4
         if (atoi(e) == 2) {
           const int rcq = tdk_raise_lds_limit(reinterpret_cast<const void*>(&rq::rcd_quad<2, TI, T>), 160 * 1024, "tdk_rcd(hipFuncSetAttribute)");

@@ -26,6 +26,15 @@
 
 namespace rq {
 
+#ifdef TDK_RCD_TIMING
+// experiments: clock deltas of wave 0 of one mid-frame workgroup per phase of a step, summed over its steps (profiles/rcd_phase_exp.py):
+// 0 slide + new rows (two barriers), 1 steps 2.1 / 1.1 / 4.1, 2 steps 1.2 / 4.2, 3 step 3.1, 4 step 5.1, 5 step 5.2 + stores;
+// 8 + k: the same phase up to the ARRIVAL at its closing barrier (the rest is waiting for the other waves)
+#define RQ_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == 300u) { const unsigned long long t_ = clock64(); atomicAdd(&g_rcd_phase_cycles[k], t_ - rq_t0); if ((k) < 8) rq_t0 = t_; } } while (0)
+#else
+#define RQ_MARK(k)
+#endif
+
 using namespace rs;  // plane geometry (CFA_B ... COL_B, *_L, *_W), LAG_*, RB, TWS, HALO, PAD, fdiv2, lmask, keep, SLOW / FASTM / INNER, slot16, Pair
 
 constexpr int HALO = rs::HALO;  // (declared here: rcd.hip's tile kernel has a constant of the same name)
@@ -37,7 +46,7 @@ template <int CPL> struct Geo {
   static constexpr int LPR = 128 / CPL;  // lanes per row
   static constexpr int NT = RB * LPR;    // threads
   static constexpr int HPL = CPL / 2;    // entries of a half-density plane row per lane = sites of one kind per lane
-  static constexpr int WPE = 3 * NT / 256;  // waves per SIMD with three workgroups per CU
+  static constexpr int WPE = WG_PER_CU * NT / 256;  // waves per SIMD with three workgroups per CU
   static constexpr int SLIDE_PT = (SLIDE_SLOTS + NT - 1) / NT;  // float4 slide slots per thread (the last round for 128 threads)
   static_assert(SLIDE_SLOTS - (SLIDE_PT - 1) * NT == 128, "the last slide round is two whole waves");
 };
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
   constexpr int NT = G::NT, LPR = G::LPR, HPL = G::HPL, SLIDE_PT = G::SLIDE_PT;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane / LPR, q = lane % LPR;
-  const int rr = wv + 4 * hf;  // row of this thread in a step's block
+  const int rr = wv + (RB / 2) * hf;  // row of this thread in a step's block
   for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
     ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
     __syncthreads();
@@ -499,6 +508,9 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
   prefetch(0);
   bool ok1 = false, ok2 = false;  // range verdicts of the two previous blocks
 
+#ifdef TDK_RCD_TIMING
+  unsigned long long rq_t0 = clock64();
+#endif
   for (int b = 0; b < nsteps; b++) {
     // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
     if (b > 0) {
@@ -545,6 +557,7 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
     }
     // the rows of every step of this block (lags 1 .. 10 behind rows gy0 + 8 b .. + 7) inside every step's row range
     const bool inner = inner_cols && gy0 + RB * b - LAG_52 >= 4 && gy0 + RB * b + RB - 1 - LAG_21 <= h - 5;
+    RQ_MARK(0);
 
     const int gyb = gy0 + RB * b + rr;  // frame row of this thread's lag-0 site
     const int orow = RB * b - LAG_52 + rr, gyo = gy0 + orow;
@@ -558,14 +571,23 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
 #define RQ_STEP(MODEV, PEV)                                              \
   do {                                                                   \
     q_step_2_1_1_1_4_1<CPL, MODEV, PEV, TI>(t, gyb, in);                 \
+    RQ_MARK(9);                                                          \
     wg_barrier();                                                        \
+    RQ_MARK(1);                                                          \
     q_step_1_2_4_2<CPL, MODEV, PEV>(t, gyb);                             \
+    RQ_MARK(10);                                                         \
     wg_barrier();                                                        \
+    RQ_MARK(2);                                                          \
     q_step_3_1<CPL, MODEV, PEV>(t, gyb);                                 \
+    RQ_MARK(11);                                                         \
     wg_barrier();                                                        \
+    RQ_MARK(3);                                                          \
     q_step_5_1<CPL, MODEV, PEV>(t, gyb, rel51);                          \
+    RQ_MARK(12);                                                         \
     wg_barrier();                                                        \
+    RQ_MARK(4);                                                          \
     q_step_5_2_out<CPL, MODEV, PEV, T>(t, red_row, dst, st, stm);        \
+    RQ_MARK(5);                                                          \
   } while (0)
     if constexpr (AP) {
       if (inner) { if (pe) RQ_STEP(AINNER, 1); else RQ_STEP(AINNER, 0); }

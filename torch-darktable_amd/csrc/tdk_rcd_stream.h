@@ -24,7 +24,15 @@
 
 namespace rs {
 
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RS_RB)
+// experiment: TDK_RS_RB rows per step (16: half the barriers and slides per row, two workgroups per CU); rq::rcd_quad only -- the
+// host takes it for every strip launch of such a build
+constexpr int RB = TDK_RS_RB, NT = 512, TWS = 108, HALO = 10;
+constexpr int WG_PER_CU = 2;
+#else
 constexpr int RB = 8, NT = 512, TWS = 108, HALO = 10;
+constexpr int WG_PER_CU = 3;
+#endif
 
 // planes: base (floats), live rows (rows older than the step's 8 new ones that a reader still needs), writer's lag
 constexpr int PAD = 8;
@@ -43,7 +51,7 @@ constexpr int COL_B = PQ_B + (PQ_L + RB) * 64;
 constexpr int LDS_FLOATS = COL_B + (COL_L + RB) * 64 + PAD;
 constexpr int VERDICT_WORDS = 4 * 8;  // [step & 3][wave]
 constexpr size_t LDS_BYTES = (size_t)(LDS_FLOATS + VERDICT_WORDS) * sizeof(float);
-static_assert(3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
 
 // lags of the steps (rows behind the newest CFA row)
 constexpr int LAG_21 = 1, LAG_11 = 3, LAG_41 = 3, LAG_12 = 4, LAG_42 = 4, LAG_31 = 5, LAG_51 = 7, LAG_52 = 10;

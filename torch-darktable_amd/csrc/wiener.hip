@@ -527,6 +527,67 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
   }
 }
 
+// Finish of the Lab hand-over chain (color.hip: lum_lab_extract): fold + normalise as above, then the lightness of the pixel
+// modify_log_luminance would produce -- WITHOUT producing it.  L' = clamp(exp(log L'), 0, 1) with the pixel's chroma (a, b) is
+// converted to LINEAR RGB (three cubes and a 3 x 3 matrix, no transcendental); the reference clips the sRGB-encoded pixel to
+// [0, 1] (device_conversions.h:213-225), the encoding is monotone with 0 -> 0 and 1 -> 1, so a pixel is clipped iff a linear
+// channel leaves [0, 1].  Not clipped (all but ~5e-4 of the pixels of a natural frame): the result's lightness is L' and its
+// chroma is unchanged.  Clipped: L, a, b are re-derived from the clipped linear pixel (three cube roots) and (a, b) is rewritten.
+// Output: the fp32 lightness plane of the result (what compute_luminance(result) gives) + the (a, b) plane, for tdk_bilateral_lab.
+template <int VEC>
+__global__ __launch_bounds__(256) void wiener_finish_lab(const float* __restrict__ slabs, float* __restrict__ ab, float* __restrict__ lum_out, int W, int H,
+                                                         Geom g, WParams prm) {
+  const int u0 = -g.jmin * g.s;
+  const size_t slab_sz = (size_t)g.RSXP * g.RSY;
+  const int ngroup = W / VEC;
+  const bool vfold = fold_vec_ok(slabs, g);
+  for (int y = blockIdx.y; y < H; y += gridDim.y) {
+    const RowPtrs rp = row_ptrs(slabs, y, u0, g, slab_sz, prm);
+    for (int gi_ = blockIdx.x * 256 + threadIdx.x; gi_ < ngroup; gi_ += gridDim.x * 256) {
+      const int x0 = gi_ * VEC;
+      const size_t gi = (size_t)y * ngroup + gi_;
+      float c2[2 * VEC], l[VEC], accs[VEC];
+      if constexpr (VEC == 4) { s4_io<float>::load(ab, 2 * gi, c2); s4_io<float>::load(ab, 2 * gi + 1, c2 + 4); }
+      else { c2[0] = ab[2 * gi]; c2[1] = ab[2 * gi + 1]; }
+      if (VEC == 4 && vfold) {
+        const float4 a4 = fold4x4(rp.row0, rp.row1, x0, u0, g, slab_sz);
+        accs[0] = a4.x;
+        if constexpr (VEC == 4) { accs[1] = a4.y; accs[2] = a4.z; accs[3] = a4.w; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) accs[k] = fold4(rp.row0, rp.row1, x0 + k, u0, g, slab_sz);
+      }
+      f3 lin[VEC];
+      bool clipped = false;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const float mask = prm.m1[(x0 + k) & (g.s - 1)] * rp.my;
+        l[k] = fmaxf(0.0f, fminf(1.0f, tdk_exp(accs[k] * __builtin_amdgcn_rcpf(mask + 1e-15f))));
+        lin[k] = xyz_to_rgb_lin(cA::lab_to_xyz(mk3(l[k], c2[2 * k], c2[2 * k + 1])));
+        clipped = clipped || !(lin[k].x >= 0.0f && lin[k].x <= 1.0f && lin[k].y >= 0.0f && lin[k].y <= 1.0f && lin[k].z >= 0.0f && lin[k].z <= 1.0f);
+      }
+      const bool any_clipped = __builtin_amdgcn_ballot_w64(clipped) != 0;
+      if (any_clipped) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const f3 q = lin[k];
+          if (!(q.x >= 0.0f && q.x <= 1.0f && q.y >= 0.0f && q.y <= 1.0f && q.z >= 0.0f && q.z <= 1.0f)) {
+            const f3 lab = cA::xyz_to_lab(rgb_to_xyz_lin(clip3(q)));
+            l[k] = fmaxf(0.0f, lab.x);
+            c2[2 * k] = lab.y; c2[2 * k + 1] = lab.z;
+          }
+        }
+        if (clipped) {
+          if constexpr (VEC == 4) { s4_io<float>::store(ab, 2 * gi, c2); s4_io<float>::store(ab, 2 * gi + 1, c2 + 4); }
+          else { ab[2 * gi] = c2[0]; ab[2 * gi + 1] = c2[1]; }
+        }
+      }
+      if constexpr (VEC == 4) s4_io<float>::store(lum_out, gi, l);
+      else lum_out[gi] = l[0];
+    }
+  }
+}
+
 // Finish for three planes at once: fold the slabs of each channel, normalise, write interleaved RGB.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void wiener_finish3(const float* __restrict__ slabs, T* __restrict__ out, int W, int H, Geom g, WParams prm) {
@@ -868,6 +929,28 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
   return TDK_OK;
 }
 
+// The Lab hand-over form of Wiener.process_log_luminance: extract log-L + (a, b) -> tiles -> wiener_finish_lab.
+template <int K>
+int launch_log_luminance_lab(const void* rgb_in, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_, float* lum_out,
+                             float* ab_out) {
+  TDK_REQUIRE(window_table_ok<K>(), "tdk_wiener: the compiled-in window table does not match make_window()");
+  const bool ysk = use_ystream(K, ov);
+  const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
+  const WParams prm = make_params<K>(g, ov);
+  float* slabs = reinterpret_cast<float*>(workspace);
+  float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
+  int rc = tdk_compute_log_luminance_lab(rgb_in, plane, ab_out, (int64_t)W * H, eps, dtype, reinterpret_cast<tdk_stream_t>(st_));
+  if (rc != TDK_OK) return rc;
+  rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
+  if (rc != TDK_OK) return rc;
+  const dim3 fgrid((unsigned)tdk_div_up((W % 4) == 0 ? W / 4 : W, 256), (unsigned)(H < 32768 ? H : 32768));
+  if ((W % 4) == 0 && tdk_aligned(ab_out, 16) && tdk_aligned(lum_out, 16))
+    TDK_LAUNCH("tdk_wiener(finish+lab)", (wiener_finish_lab<4>), fgrid, dim3(256), 0, st_, slabs, ab_out, lum_out, W, H, g, prm);
+  else
+    TDK_LAUNCH("tdk_wiener(finish+lab)", (wiener_finish_lab<1>), dim3((unsigned)tdk_div_up(W, 256), fgrid.y), dim3(256), 0, st_, slabs, ab_out, lum_out, W, H, g, prm);
+  return TDK_OK;
+}
+
 }  // namespace
 
 #if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
@@ -929,4 +1012,17 @@ TDK_EXPORT int tdk_wiener_log_luminance_lum(const void* rgb_in, void* rgb_out, v
     TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 16>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, lum_log_mode, lum_eps)));
   TDK_DISPATCH_DTYPE(dtype, T, return (launch_log_luminance<T, 32>(rgb_in, rgb_out, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, lum_log_mode, lum_eps)));
   return TDK_OK;
+}
+
+TDK_EXPORT int tdk_wiener_log_luminance_lab(const void* rgb_in, void* workspace, int width, int height, int tile_size, int overlap_factor, const float* sigma,
+                                            float eps, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream) {
+  TDK_REQUIRE(rgb_in && workspace && sigma && lum_out && ab_out, "tdk_wiener_log_luminance_lab: null pointer");
+  TDK_REQUIRE(tile_size == 16 || tile_size == 32, "tile_size must be 16 or 32, got %d", tile_size);
+  TDK_REQUIRE(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8, "overlap_factor must be 2, 4, or 8");
+  TDK_REQUIRE(width >= tile_size && height >= tile_size, "tdk_wiener_log_luminance_lab: image %dx%d smaller than the tile size %d", width, height, tile_size);
+  TDK_REQUIRE(eps > 0.0f, "Epsilon must be positive");
+  TDK_REQUIRE(dtype == TDK_F32 || dtype == TDK_F16, "unsupported dtype tag %d", dtype);
+  hipStream_t s = tdk_stream(stream);
+  if (tile_size == 16) return launch_log_luminance_lab<16>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out);
+  return launch_log_luminance_lab<32>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out);
 }

@@ -77,6 +77,11 @@ class Bilateral:
         assert input_image.dim() == 3, f'image must have 3 dimensions, got {input_image.shape}'
         return self._bilateral.process_rgb(input_image, float(detail), luminance, metrics)
 
+    def process_lab(self, luminance: torch.Tensor, chroma: torch.Tensor, detail: float, *, out_dtype: torch.dtype = torch.float32, metrics=None) -> torch.Tensor:
+        """process_rgb for pixels handed over as Lab by denoise.Wiener.process_log_luminance_lab: float32 (H, W) lightness +
+        float32 (H, W, 2) chroma in, (H, W, 3) RGB of `out_dtype` out."""
+        return self._bilateral.process_lab(luminance, chroma, float(detail), out_dtype, metrics)
+
     def process_log_rgb(self, input_image: torch.Tensor, detail: float, eps: float = 1e-6, *, luminance: torch.Tensor | None = None, metrics=None) -> torch.Tensor:
         return self._bilateral.process_log_rgb(input_image, float(detail), eps, luminance, metrics)
 

@@ -683,6 +683,32 @@ class Wiener(_Workspace):
     return out
 
 
+  def process_log_luminance_lab(self, image: torch.Tensor, noise_sigmas: torch.Tensor, eps: float = 1e-4, luminance_out: torch.Tensor | None = None,
+                                chroma_out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Lab hand-over form of process_log_luminance (include/tdk_hip.h: tdk_wiener_log_luminance_lab): instead of the denoised RGB
+    image it returns (luminance, chroma) = the float32 (H, W) plane compute_luminance(denoised) and the float32 (H, W, 2) plane
+    of the denoised pixels' Lab (a, b) -- what Bilateral.process_lab takes.  The RGB image between the two stages is never
+    formed: one colour round trip for the two stages instead of two (tolerance of the colour operators, not bit for bit)."""
+    _check_rgb(image, 'image', allow_half=True)
+    _require(image.device == self._device, 'input device mismatch')
+    _require(image.size(0) == self._height and image.size(1) == self._width, 'Input dimensions must match workspace size')
+    _require(eps > 0.0, 'Epsilon must be positive')
+    x = image.contiguous()
+    sig = noise_sigmas.to(device=x.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+    lum = luminance_out if luminance_out is not None else torch.empty((self._height, self._width), dtype=torch.float32, device=x.device)
+    ab = chroma_out if chroma_out is not None else torch.empty((self._height, self._width, 2), dtype=torch.float32, device=x.device)
+    _require(lum.dtype == torch.float32 and lum.is_contiguous() and lum.device == x.device and tuple(lum.shape) == (self._height, self._width),
+             'luminance_out must be a contiguous float32 (H, W) tensor on the image device')
+    _require(ab.dtype == torch.float32 and ab.is_contiguous() and ab.device == x.device and tuple(ab.shape) == (self._height, self._width, 2),
+             'chroma_out must be a contiguous float32 (H, W, 2) tensor on the image device')
+    with torch.cuda.device(x.device):
+      nbytes = lib.tdk_wiener_log_luminance_workspace_bytes(self._width, self._height, self._tile_size, self._overlap_factor)
+      ws = self._workspace(nbytes, x.device)
+      check(lib.tdk_wiener_log_luminance_lab(_ptr(x), _ptr(ws), self._width, self._height, self._tile_size, self._overlap_factor, _ptr(sig), float(eps),
+                                             _dtype_tag(x), _ptr(lum), _ptr(ab), _stream()))
+    return lum, ab
+
+
 def create_wiener(device, width: int, height: int, overlap_factor: int = 4, tile_size: int = 32) -> Wiener:
   """reference torch_darktable_extension.pyi:171-177 (declared there; the reference's extension.cpp never
   registers it -- its Python helper denoise.create_wiener builds the wrapper class instead)."""
@@ -766,6 +792,24 @@ class Bilateral(_Workspace):
                  and tuple(luminance.shape) == (self._height, self._width), 'luminance must be a contiguous float32 (H, W) tensor on the image device')
       check(lib.tdk_bilateral_rgb_ex(_ptr(x), _ptr(luminance), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r,
                                      float(detail), int(log_mode), float(eps), _dtype_tag(x), flags, _stream()))
+    if metrics is not None:
+      metrics.add(out)
+    return out
+
+  def process_lab(self, luminance: torch.Tensor, chroma: torch.Tensor, detail: float, out_dtype: torch.dtype = torch.float32,
+                  metrics: 'MetricsAccumulator | None' = None) -> torch.Tensor:
+    """process_rgb for a pixel that arrives as Lab (Wiener.process_log_luminance_lab): filter the float32 (H, W) lightness plane
+    and write modify_luminance's result -- clip(lab_to_rgb(filtered L, a, b)) -- as an (H, W, 3) image of out_dtype."""
+    _require(luminance.is_cuda and luminance.dtype == torch.float32 and luminance.is_contiguous() and tuple(luminance.shape) == (self._height, self._width),
+             'luminance must be a contiguous float32 (H, W) CUDA tensor')
+    _require(chroma.dtype == torch.float32 and chroma.is_contiguous() and chroma.device == luminance.device
+             and tuple(chroma.shape) == (self._height, self._width, 2), 'chroma must be a contiguous float32 (H, W, 2) tensor on the same device')
+    _require(out_dtype in (torch.float32, torch.float16), 'out_dtype must be float32 or float16')
+    out = torch.empty((self._height, self._width, 3), dtype=out_dtype, device=luminance.device)
+    with torch.cuda.device(luminance.device):
+      ws, flags = self._prepared_workspace(lib.tdk_bilateral_rgb_workspace_bytes(self._width, self._height, self._sigma_s, self._sigma_r), luminance.device)
+      check(lib.tdk_bilateral_lab(_ptr(luminance), _ptr(chroma), _ptr(out), _ptr(ws), self._width, self._height, self._sigma_s, self._sigma_r, float(detail),
+                                  _dtype_tag(out), flags, _stream()))
     if metrics is not None:
       metrics.add(out)
     return out
