@@ -190,6 +190,41 @@ def test_metrics_one_launch_equals_two_launches(td, dev):
     assert torch.equal(acc.finish(), torch.zeros(5, device=dev))
 
 
+def test_metrics_one_launch_on_many_grids(td, dev):
+    """The run-time side of tests/test_isa_contract.py: the fence-less last-ticket hand-off of tdk_image_metrics against the
+    two-launch form on grids from ONE workgroup to the 4 096-workgroup cap (more workgroups than accumulator rows: rows shared),
+    repeated back to back on one accumulator -- a stale row, a lost add or a ticket left behind shows as a mismatch or a
+    non-zero accumulator."""
+    import ctypes as C
+
+    from torch_darktable._native import lib
+
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bounds = torch.tensor([0.0, 1.0], device=dev)
+    acc1, acc2 = torch.zeros(8192, device=dev), torch.zeros(8192, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator(device=dev).manual_seed(11)
+    # grid = ceil(samples / 512), samples = ceil(w / stride) * ceil(h / stride)
+    shapes = [(16, 16, 1), (23, 22, 1), (64, 64, 2), (100, 300, 1), (512, 384, 1), (700, 999, 1), (1024, 1024, 1), (1536, 2048, 2),
+              (1024, 2048, 1), (2048, 2048, 1), (3072, 4096, 8), (3072, 4096, 3)]
+    grids = set()
+    for rep in range(2):
+        for (h, w, stride) in shapes:
+            x = torch.rand(h, w, 3, generator=g, device=dev) * 1.05
+            grid = min(4096, -(-(-(-w // stride) * -(-h // stride)) // 512))
+            grids.add(grid)
+            for _ in range(3):
+                m1, m2 = torch.empty(5, device=dev), torch.empty(5, device=dev)
+                assert lib.tdk_image_metrics(p(x), w, h, stride, 1e-4, p(bounds), p(acc1), p(m1), 0, stream) == 0
+                assert lib.tdk_image_metrics_accumulate_rows(p(x), w, h, stride, 1e-4, p(bounds), p(acc2), 0, stream) == 0
+                assert lib.tdk_image_metrics_finish_reset(p(acc2), p(m2), stream) == 0
+                # up to two workgroups per accumulator row add in either order to the same bits; three or more may not
+                same = torch.equal(m1, m2) if grid <= 2048 else torch.allclose(m1, m2, rtol=2e-6, atol=0)
+                assert same, ((h, w, stride), m1, m2)
+            assert not acc1.any() and not acc2.any()
+    assert min(grids) == 1 and max(grids) == 4096 and len(grids) >= 9, sorted(grids)
+
+
 def test_bilateral_prepared_workspace_and_flags(td, dev):
     """The C ABI of the bilateral tile kernel: tdk_bilateral_prepare once + TDK_BILATERAL_PREPARED on every call == the plain
     entry points (which build the axis tables themselves) == the four-kernel path (TDK_BILATERAL_GENERAL_PATH), for the plane

@@ -82,25 +82,34 @@ __global__ void metrics_init_kernel(float* acc) {
 // into metrics[0..4]; the rows (and the ticket word in row 0) are zeroed for the next image.  AGENT_LOADS: the rows were
 // written by other workgroups of the SAME launch (float atomics, which execute at the memory side and leave nothing in L2): they
 // are read with agent-scope loads that bypass this CU's vector L1.
+// nrows: the rows that can hold anything (the launch's workgroups wrote rows 0 .. min(grid, SLOTS) - 1; the others are zero and
+// stay zero): rows j * 256 + thread with j < ceil(nrows / 256) are read -- a 12 MP frame at stride 8 touches 384 of the 1 024.
 template <bool AGENT_LOADS>
-__device__ __forceinline__ void metrics_finish_rows(float* __restrict__ acc, float* __restrict__ metrics, float (*part)[6]) {
+__device__ __forceinline__ void metrics_finish_rows(float* __restrict__ acc, float* __restrict__ metrics, float (*part)[6], int nrows) {
   static_assert(TDK_METRICS_SLOTS == 4 * 256, "four rows per thread");
+  const int nj = (nrows + 255) >> 8;  // uniform
   float v[4][6];  // all loads in flight before the first use
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int r = threadIdx.x + 256 * j;
 #pragma unroll
-    for (int k = 0; k < 6; k++) v[j][k] = AGENT_LOADS ? __hip_atomic_load(&acc[r * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[r * 8 + k];
+    for (int k = 0; k < 6; k++) v[j][k] = 0.0f;
+    if (j < nj) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[j][k] = AGENT_LOADS ? __hip_atomic_load(&acc[r * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[r * 8 + k];
+    }
   }
   float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
 #pragma unroll
     for (int k = 0; k < 6; k++) s[k] += v[j][k];
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float* row = acc + (threadIdx.x + 256 * j) * 8;
-    reinterpret_cast<float4*>(row)[0] = z;
-    reinterpret_cast<float4*>(row)[1] = z;
+    if (j < nj) {
+      const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float* row = acc + (threadIdx.x + 256 * j) * 8;
+      reinterpret_cast<float4*>(row)[0] = z;
+      reinterpret_cast<float4*>(row)[1] = z;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -156,7 +165,9 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
   __syncthreads();
   if (threadIdx.x < 6) {
     const float mine = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    atomicAdd(&acc[(ROWS ? (blockIdx.x & (TDK_METRICS_SLOTS - 1)) * 8 : 0) + threadIdx.x], mine);
+    // explicitly a relaxed agent-scope RMW: on gfx950 a memory-side global_atomic_add_f32 (tests/test_isa_contract.py pins the
+    // instruction), which the one-launch hand-off below relies on
+    __hip_atomic_fetch_add(&acc[(ROWS ? (blockIdx.x & (TDK_METRICS_SLOTS - 1)) * 8 : 0) + threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (ROWS) {
     if (finish_to) {  // kernel argument: uniform
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
       __syncthreads();
       if (last_block) {  // workgroup-uniform (LDS word)
         __syncthreads();  // `part` is reused
-        metrics_finish_rows<true>(acc, finish_to, part);  // also zeroes row 0's ticket word
+        metrics_finish_rows<true>(acc, finish_to, part, min((int)gridDim.x, TDK_METRICS_SLOTS));  // also zeroes row 0's ticket word
       }
     }
   }
@@ -189,7 +200,7 @@ __global__ void metrics_finish_kernel(const float* __restrict__ acc, float* __re
 // (tdk_image_metrics_accumulate_rows, one per image): one workgroup, stream-ordered after the adds; rows are summed in a fixed order.
 __global__ __launch_bounds__(256) void metrics_finish_reset_kernel(float* __restrict__ acc, float* __restrict__ metrics) {
   __shared__ float part[4][6];
-  metrics_finish_rows<false>(acc, metrics, part);
+  metrics_finish_rows<false>(acc, metrics, part, TDK_METRICS_SLOTS);
 }
 
 // ------------------------------------------------------------------ tonemaps
