@@ -284,3 +284,73 @@ def test_verification_paths_are_thread_local(td, dev):
         seen['mine'] = (ext._verify.rcd, ext._verify.bil)
     assert seen['other'] == (0, 0) and seen['mine'] == (ext.TDK_RCD_TILE_KERNEL, ext.TDK_BILATERAL_GENERAL_PATH)
     assert (ext._verify.rcd, ext._verify.bil) == (0, 0)
+
+
+def _isp_chain(td, dev, w, h, dtype):
+    rcd = td.RCD(dev, (w, h), td.BayerPattern.RGGB)
+    wiener = td.Wiener(dev, (w, h), overlap_factor=4, tile_size=32)
+    bil = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
+    params = td.TonemapParameters(gamma=0.75, intensity=2.0, light_adapt=1.0, vibrance=0.0)
+    lum = torch.empty((h, w), dtype=torch.float32, device=dev)
+    ab = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    acc = td.tonemap.MetricsAccumulator(dev, stride=8)
+
+    def frame(bayer):
+        rgb = rcd.process(bayer)
+        wiener.process_log_luminance_lab(rgb, 0.075, luminance_out=lum, chroma_out=ab)
+        rgb = bil.process_lab(lum, ab, 0.4, out_dtype=dtype, metrics=acc)
+        return td.reinhard_tonemap(rgb, acc.finish(), params)
+
+    return frame
+
+
+def test_frame_chain_replays_as_a_hip_graph(td, dev):
+    """DESIGN.md 2 says nothing allocates or synchronises inside an op, so a frame's whole chain (RCD -> Wiener -> bilateral + metrics
+    -> tone map; 7 launches) can be captured into a HIP graph: capture it, refill the static input with OTHER frames, replay, and
+    get the bits of the eager chain -- the metrics accumulator's ticket and rows included (they must come back to zero inside the
+    graph for the next replay)."""
+    from torch_darktable.synthetic import synthetic_bayer
+
+    h, w = 512, 768
+    frames = [synthetic_bayer(h, w, seed=80 + i, device=dev).half() for i in range(3)]
+    chain = _isp_chain(td, dev, w, h, torch.float16)
+    eager = [chain(f).clone() for f in frames]
+    static_in = frames[0].clone()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):  # warm-up on the capture's side stream: workspaces are cached per (object, stream)
+        for _ in range(2):
+            chain(static_in)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_out = chain(static_in)
+    for rep in range(2):
+        for f, want in zip(frames, eager):
+            static_in.copy_(f)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_out, want), (rep, (static_out != want).sum().item())
+
+
+def test_frame_streams_batch_replays_as_one_graph(td, dev):
+    """FrameStreams.capture: a batch of frames on three streams, fork and join included, as ONE graph; replays on refilled inputs
+    give the bits of the eager batch."""
+    from torch_darktable.sharding import FrameStreams
+    from torch_darktable.synthetic import synthetic_bayer
+
+    h, w = 384, 512
+    runner = FrameStreams(dev, lambda: _isp_chain(td, dev, w, h, torch.float16), streams=3)
+    batch_a = [synthetic_bayer(h, w, seed=90 + i, device=dev).half() for i in range(5)]
+    batch_b = [synthetic_bayer(h, w, seed=190 + i, device=dev).half() for i in range(5)]
+    want_a = [o.clone() for o in runner.run(batch_a)]
+    want_b = [o.clone() for o in runner.run(batch_b)]
+    static = [f.clone() for f in batch_a]
+    cap = runner.capture(static)
+    for rep in range(2):
+        for batch, want in ((batch_b, want_b), (batch_a, want_a)):
+            outs = cap.replay(batch)
+            torch.cuda.synchronize()
+            for i, (o, e) in enumerate(zip(outs, want)):
+                assert torch.equal(o, e), (rep, i, (o != e).sum().item())

@@ -47,7 +47,9 @@ class Wiener:
             if t is None:
                 if len(cache) >= 16:
                     cache.clear()
-                t = cache[key] = torch.full((channels,), noise, dtype=torch.float32, device=self._device)
+                # built on the host and copied from pageable memory: the copy has completed when .to() returns, so the tensor is
+                # valid on EVERY stream that later reads it (a torch.full would be a fill queued on the stream current now)
+                t = cache[key] = torch.tensor([noise] * channels, dtype=torch.float32).to(self._device)
             return t
         if isinstance(noise, torch.Tensor):
             if noise.shape != (channels,):

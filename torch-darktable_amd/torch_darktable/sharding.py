@@ -40,6 +40,7 @@ class FrameStreams:
         self.chains = [make_chain() for _ in range(streams)]
         self.streams = [torch.cuda.Stream(device) for _ in range(streams)] if streams > 1 else [None]
         self._next = 0  # the stream the next frame goes to: the rotation carries over from batch to batch
+        self._unjoined = False  # frames issued since the last join()
 
     def issue(self, frames) -> list:
         """Launch every frame's chain; returns the outputs without joining the streams (they are complete only after
@@ -55,7 +56,11 @@ class FrameStreams:
         from .torch_darktable_extension import concurrent_frames
 
         n = len(self.streams)
-        with concurrent_frames():  # the other streams' frames share the GPU with every kernel launched here
+        # a single frame with nothing else in flight would run the register-blocked RCD strips ALONE, where they are the slower
+        # variant (csrc/tdk_rcd_quad.h): tell the ops about company only when this batch (or an un-joined earlier one) provides it
+        company = len(frames) > 1 or self._unjoined
+        self._unjoined = True
+        with concurrent_frames(company):  # the other streams' frames share the GPU with every kernel launched here
             for f in frames:
                 k = self._next
                 self._next = (k + 1) % n
@@ -76,8 +81,40 @@ class FrameStreams:
         for o in outs:
             if isinstance(o, torch.Tensor):
                 o.record_stream(here)
+        self._unjoined = False
 
     def run(self, frames) -> list:
         outs = self.issue(frames)
         self.join(outs)
         return outs
+
+    def capture(self, frames) -> 'CapturedBatch':
+        """One batch -- every frame's chain on its stream, fork and join included -- captured into ONE HIP graph
+        (torch.cuda.CUDAGraph).  `frames` are the STATIC input tensors: refill them in place (copy_) and call replay() for every
+        further batch; the outputs are static tensors as well (overwritten by the next replay).  Nothing in the library allocates,
+        synchronises or keeps process-global state inside an op, so the whole chain is capturable; what a replay saves is the
+        host's launch path (57 ctypes calls per batch of 8 frames -> one graph launch).  The chains must have run once on their
+        streams before (workspaces allocated, LDS limits raised): capture() does that warm-up itself."""
+        import torch
+
+        for _ in range(2):  # warm-up outside the capture: workspace allocation, hipFuncSetAttribute, cached scalars
+            self.run(frames)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self.run(frames)
+        return CapturedBatch(graph, list(frames), outs)
+
+
+class CapturedBatch:
+    """A FrameStreams batch as a replayable HIP graph: `inputs` and `outputs` are the static tensors of the capture."""
+
+    def __init__(self, graph, inputs, outputs):
+        self.graph, self.inputs, self.outputs = graph, inputs, outputs
+
+    def replay(self, new_inputs=None) -> list:
+        if new_inputs is not None:
+            for dst, src in zip(self.inputs, new_inputs):
+                dst.copy_(src)
+        self.graph.replay()
+        return self.outputs

@@ -537,11 +537,18 @@ def compute_image_metrics(images: Sequence[torch.Tensor], stride: int = 8, min_g
   acc = _METRICS_STATE.get(key)
   if acc is None:
     acc = _METRICS_STATE[key] = MetricsAccumulator(dev)
+  for img in images:  # every image is checked before the first one is added: a bad list leaves nothing behind in the cached accumulator
+    _check_rgb(img, allow_half=True)
+    _require(img.device == dev, f'image is on {img.device}, the first one on {dev}')
   acc.stride, acc.min_gray = int(stride), float(min_gray)
   acc.bounds = bounds if bounds is not None else _unit_bounds(dev)
-  for img in images:
-    acc.add(img)
-  return acc.finish()
+  try:
+    for img in images:
+      acc.add(img)
+    return acc.finish()
+  except Exception:
+    acc.reset()
+    raise
 
 
 class MetricsAccumulator:
@@ -551,7 +558,9 @@ class MetricsAccumulator:
   compute_image_metrics(images) == [acc.add(i) for i in images]; acc.finish().
   The kernel of the LAST image added also does the finish (tdk_image_metrics: one launch, the workgroup that draws the last
   ticket sums the rows), so the usual one image per frame costs one launch; for that the launch of an added image is issued
-  when the next image arrives or at finish() -- on the stream that is current THEN."""
+  when the next image arrives or at finish() -- on the stream that is current THEN (if that is another stream than the one
+  current at add(), it first waits for the work queued there: the image's producer).  Contract: an added image must not be written
+  to (nor its storage reused) until the next add() / finish(): the accumulator keeps a reference, not a copy."""
 
   def __init__(self, device, stride: int = 8, min_gray: float = 1e-4, bounds: torch.Tensor | None = None):
     device = torch.device(device)
@@ -560,9 +569,14 @@ class MetricsAccumulator:
     self.bounds = bounds.to(device=device, dtype=torch.float32).contiguous() if bounds is not None else _unit_bounds(device)
     self.acc = torch.zeros(8192, dtype=torch.float32, device=device)  # TDK_METRICS_ACC_FLOATS: 1024 rows of 8
     self._pending: torch.Tensor | None = None
+    self._pending_stream = None  # the stream that was current when the pending image was added
 
   def _launch(self, x: torch.Tensor, metrics: torch.Tensor | None) -> None:
     with torch.cuda.device(x.device):
+      here = torch.cuda.current_stream(x.device)
+      if self._pending_stream is not None and self._pending_stream != here:
+        here.wait_stream(self._pending_stream)  # the image was produced on the stream of its add()
+      self._pending_stream = None
       try:
         if metrics is None:
           check(lib.tdk_image_metrics_accumulate_rows(_ptr(x), x.size(1), x.size(0), self.stride, self.min_gray, _ptr(self.bounds), _ptr(self.acc),
@@ -575,12 +589,17 @@ class MetricsAccumulator:
         raise
 
   def add(self, image: torch.Tensor) -> None:
-    _check_rgb(image, allow_half=True)
-    _require(image.device == self.acc.device, f'image is on {image.device}, the accumulator on {self.acc.device}')
+    try:
+      _check_rgb(image, allow_half=True)
+      _require(image.device == self.acc.device, f'image is on {image.device}, the accumulator on {self.acc.device}')
+    except Exception:
+      self.reset()  # a rejected image ends the list: nothing of it may leak into the next one
+      raise
     if self._pending is not None:
       pending, self._pending = self._pending, None
       self._launch(pending, None)
     self._pending = image.contiguous()
+    self._pending_stream = torch.cuda.current_stream(image.device)
 
   def finish(self) -> torch.Tensor:
     metrics = torch.empty(5, dtype=torch.float32, device=self.acc.device)
@@ -594,6 +613,7 @@ class MetricsAccumulator:
 
   def reset(self) -> None:
     self._pending = None
+    self._pending_stream = None
     self.acc.zero_()
 
 
