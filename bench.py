@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the frames of a batch are spread over (each with its own workspaces)')
     ap.add_argument('--chain', choices=['lab', 'rgb'], default='lab',
                     help='isp: how the pixel travels from the denoiser to the local-contrast stage: lab = lightness + chroma planes (one colour round trip), rgb = the intermediate RGB image')
+    ap.add_argument('--graph', action='store_true', help='replay each step as one captured HIP graph (measurement option; no live per-kernel timing)')
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--height', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle run (and with it the parity check)')
@@ -491,6 +492,14 @@ def main(argv=None):
         last[0] = runner.issue(inputs)
 
     use_timer = not args.no_kernel_timer
+    if args.graph:
+        # one step = one replay of the batch captured as a HIP graph (FrameStreams.capture): the host launches one graph instead of
+        # ~57 kernels.  Events cannot bracket a kernel inside a graph, so this mode carries no live roofline kernel time.
+        use_timer = False
+        captured = runner.capture(inputs)
+
+        def step():  # noqa: F811
+            last[0] = captured.replay()
     # Untimed profiling pass, BEFORE the warm-up (so that the W warm-up steps run directly into the timed region): every launch of
     # one step bracketed by events -> the per-kernel table and the dominant kernel.  In the timed region only THAT kernel keeps its
     # events (measured live, on its launch stream), so the throughput number is not taxed by ~100 event pairs per step.
@@ -639,6 +648,7 @@ def main(argv=None):
         'config': {
             'workload': workload_text,
             'width': w, 'height': h, 'frames_per_gpu_per_step': frames, 'streams_per_gpu': nstreams, 'storage': storage, 'arithmetic': 'f32',
+            'chain': args.chain if args.workload == 'isp' else None, 'issue': 'hip graph replay per step' if args.graph else 'eager launches',
             'denoiser': 'Wiener (the reference has no nlmeans / wavelet denoiser)', 'sharding': 'independent frames per GPU, no collective (gloo barrier + max of the timing only)'
             + (' -- REHEARSAL: ranks share GPUs (TDK_BENCH_SHARE_GPU=1), not a scaling measurement' if shared else ''),
             'cpus_pinned': pinned,
