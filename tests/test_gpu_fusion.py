@@ -140,12 +140,15 @@ def test_concurrent_frames_context(td, dev):
         plain = ws.process(bayer).clone()
         with ext.concurrent_frames():
             quad = ws.process(bayer).clone()
-            with ext.verification_paths(rcd_tiles=True):  # both flags at once: the tile kernel wins (it serves any frame)
+        assert torch.equal(plain, quad)  # (float16: both strip kernels in the approximate flavour)
+        with ext.verification_paths(rcd_exact=True):  # the tile kernel is always the exact flavour
+            exact = ws.process(bayer).clone()
+            with ext.concurrent_frames(), ext.verification_paths(rcd_tiles=True, rcd_exact=True):  # both flags at once: the tile kernel wins (it serves any frame)
                 tiles = ws.process(bayer).clone()
-        assert torch.equal(plain, quad) and torch.equal(plain, tiles)
+        assert torch.equal(exact, tiles)
     out = torch.empty(h, w, 3, device=dev)
     b32 = synthetic_bayer(h, w, seed=5, device=dev)
-    rc = lib.tdk_rcd_ex(C.c_void_p(b32.data_ptr()), C.c_void_p(out.data_ptr()), None, w, h, C.c_uint32(0x94949494), 0, 4, None)
+    rc = lib.tdk_rcd_ex(C.c_void_p(b32.data_ptr()), C.c_void_p(out.data_ptr()), None, w, h, C.c_uint32(0x94949494), 0, 8, None)
     assert rc != 0 and b'unknown flags' in lib.tdk_last_error()
 
 

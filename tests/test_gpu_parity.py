@@ -328,13 +328,15 @@ def test_rcd_fp16_extremes_stay_on_the_exact_path(td, oracle, dev, scene):
     # neighbour: there the bound is one binary16 ulp + 2e-7 * (largest sample within 4 pixels)
     with np.errstate(all='ignore'):
         fast = npy(td.RCD(dev, (w, h), td.BayerPattern.RGGB).process(gpu(b16, dev)))
-    assert np.isfinite(fast[np.isfinite(ref32)]).all()
+    inside = np.abs(ref32) < 65000.0  # (beyond, the oracle's own float32 result rounds to binary16 infinity: up to 95 760 next to the 65 504 block)
+    assert np.isfinite(fast[inside]).all()
     from scipy.ndimage import maximum_filter
     near = maximum_filter(b16[:, :, 0].astype(np.float32), size=9)[:, :, None]
     g, r = fast.astype(np.float32), ref.astype(np.float32)
-    ok = np.isfinite(r)
-    d = np.where(ok, np.abs(g - r), 0.0)
-    tol = half_ulp(np.maximum(np.abs(g), np.where(ok, np.abs(r), 0.0))) + np.where(near > 100.0, 2e-7 * near, 0.0)
+    ok = np.isfinite(r) & inside
+    with np.errstate(all='ignore'):
+        d = np.where(ok, np.abs(g - r), 0.0)
+    tol = half_ulp(np.maximum(np.where(ok, np.abs(g), 0.0), np.where(ok, np.abs(r), 0.0))) + np.where(near > 100.0, 2e-7 * near, 0.0)
     over = (d > tol).any(-1)
     assert over.mean() <= 1e-5, f'{over.sum()} pixels beyond the bound, first at {np.argwhere(over)[:5].tolist()}, max |d| {d.max()}'
 
