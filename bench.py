@@ -109,13 +109,92 @@ def cpu_slices(n: int) -> list[list[int]]:
     return [cores[(r * per) % len(cores):(r * per) % len(cores) + per] for r in range(n)]
 
 
+def _parse_cpulist(text: str) -> list[int]:
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs: str = '/sys') -> list[int | None]:
+    """NUMA node of every GPU, in the order of the KFD topology (= the HIP device order unless *_VISIBLE_DEVICES re-maps it, which
+    is applied here when it is a plain index list).  Read from sysfs only -- no HIP call, so a rank can pin itself before it touches
+    the GPU: topology node -> PCI address (domain, location_id) -> /sys/bus/pci/devices/<bdf>/numa_node.  None where unknown."""
+    base = Path(sysfs) / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    nodes = []
+    try:
+        dirs = sorted((d for d in base.iterdir() if d.name.isdigit()), key=lambda d: int(d.name))
+    except OSError:
+        return []
+    for d in dirs:
+        try:
+            props = dict(ln.split()[:2] for ln in (d / 'properties').read_text().splitlines() if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) == 0:
+            continue  # a CPU node of the topology
+        dom, loc = int(props.get('domain', '0')), int(props.get('location_id', '0'))
+        bdf = f'{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}'
+        try:
+            node = int((Path(sysfs) / 'bus' / 'pci' / 'devices' / bdf / 'numa_node').read_text())
+        except (OSError, ValueError):
+            node = -1
+        nodes.append(node if node >= 0 else None)
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        spec = os.environ.get(var, '')
+        if spec and all(t.strip().isdigit() for t in spec.split(',')):
+            nodes = [nodes[int(t)] if int(t) < len(nodes) else None for t in spec.split(',')]
+    return nodes
+
+
+def numa_cpu_slices(n: int, sysfs: str = '/sys', allowed: list[int] | None = None) -> list[list[int]]:
+    """Cores for each of n local ranks (rank r drives GPU r): the cores of ITS GPU's NUMA node, shared evenly among the ranks
+    whose GPUs sit on that node; ranks whose node is unknown (no sysfs entry, a container that hides it) get the plain index
+    split of cpu_slices().  Launch latency is host work on the path to the GPU's PCIe root: issuing from the remote socket adds
+    an inter-socket hop to every doorbell and every event query."""
+    cores = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    per = max(1, len(cores) // n)
+    fallback = [cores[(r * per) % len(cores):(r * per) % len(cores) + per] for r in range(n)]
+    gpu_nodes = gpu_numa_nodes(sysfs)
+    out: list[list[int] | None] = [None] * n
+    by_node: dict[int, list[int]] = {}
+    for r in range(n):
+        node = gpu_nodes[r] if r < len(gpu_nodes) else None
+        if node is not None:
+            by_node.setdefault(node, []).append(r)
+    for node, ranks_here in by_node.items():
+        try:
+            node_cpus = [c for c in _parse_cpulist((Path(sysfs) / 'devices' / 'system' / 'node' / f'node{node}' / 'cpulist').read_text()) if c in set(cores)]
+        except OSError:
+            node_cpus = []
+        share = len(node_cpus) // len(ranks_here)
+        if share < 1:
+            continue
+        for i, r in enumerate(ranks_here):
+            out[r] = node_cpus[i * share:(i + 1) * share]
+    return [out[r] if out[r] else fallback[r] for r in range(n)]
+
+
 def pin_self() -> list[int] | None:
+    """Pin this rank to its cores before it starts a thread or touches the GPU: TDK_BENCH_CPUS from a self-launching parent
+    (--pin-cpus), else -- under an external launcher (torchrun) with more than one local rank -- the NUMA-aware slice of this
+    rank computed here from LOCAL_RANK / LOCAL_WORLD_SIZE (TDK_BENCH_NO_PIN=1 switches that off)."""
     spec = os.environ.get('TDK_BENCH_CPUS')
-    if not spec:
+    try:
+        if spec:
+            cpus = [int(c) for c in spec.split(',')]
+        else:
+            lws = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+            if lws <= 1 or os.environ.get('TDK_BENCH_NO_PIN') or os.environ.get('TDK_BENCH_SELF_LAUNCHED'):
+                return None
+            cpus = numa_cpu_slices(lws, os.environ.get('TDK_BENCH_SYSFS', '/sys'))[int(os.environ.get('LOCAL_RANK', '0')) % lws]
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError):
         return None
-    cpus = [int(c) for c in spec.split(',')]
-    os.sched_setaffinity(0, cpus)
-    return cpus
 
 
 def launch_ranks(args, argv) -> int:
@@ -132,7 +211,7 @@ def launch_ranks(args, argv) -> int:
     env.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'TDK_BENCH_SELF_LAUNCHED': '1'})
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     procs = []
-    slices = cpu_slices(n) if args.pin_cpus else [None] * n
+    slices = numa_cpu_slices(n, os.environ.get('TDK_BENCH_SYSFS', '/sys')) if args.pin_cpus else [None] * n
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         if slices[r]:

@@ -32,6 +32,23 @@ def main(path):
         per_step = [round(buf[k] / 22) for k in range(16)]
         print(json.dumps({'case': name, 'cycles_per_step_incl_wait': per_step[:6], 'sum': sum(per_step[:6]),
                           'cycles_to_barrier_arrival': per_step[9:13]}))
+        if hasattr(lib, 'tdk_debug_rcd_wg_times'):
+            # start / end of every workgroup (100 MHz wall clock): launch span, workgroup lifetimes by strip / segment class
+            tb = (C.c_ulonglong * 2048)()
+            lib.tdk_debug_rcd_wg_times(tb)
+            nstrips, nwg = 38, 760
+            t = [(tb[2 * b], tb[2 * b + 1]) for b in range(nwg)]
+            t0 = min(a for a, _ in t)
+            us = lambda ticks: round(ticks / 100.0, 1)
+            life = [us(e - a) for a, e in t]
+            cls = {'interior': [], 'border strip (0, 37)': [], 'first / last segment': []}
+            for b in range(nwg):
+                strip, seg = b % nstrips, b // nstrips
+                key = 'border strip (0, 37)' if strip in (0, nstrips - 1) else ('first / last segment' if seg in (0, nwg // nstrips - 1) else 'interior')
+                cls[key].append(life[b])
+            print(json.dumps({'case': name, 'launch_span_us': us(max(e for _, e in t) - t0), 'last_start_us': us(max(a for a, _ in t) - t0),
+                              'lifetime_us': {k: {'n': len(v), 'min': min(v), 'median': sorted(v)[len(v) // 2], 'max': max(v)} for k, v in cls.items()},
+                              'end_us_percentiles': [us(sorted(e for _, e in t)[int(q * (nwg - 1))] - t0) for q in (0.1, 0.5, 0.9, 0.99, 1.0)]}))
 
 
 if __name__ == '__main__':

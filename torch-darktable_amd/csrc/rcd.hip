@@ -35,6 +35,11 @@ __device__ unsigned long long g_rcd_phase_cycles[16];
 #define RCD_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1000u ? 1500u : 3u)) { const unsigned long long t_ = clock64(); atomicAdd(&g_rcd_phase_cycles[k], t_ - rcd_t0); rcd_t0 = t_; } } while (0)
 #define RCD_T0_PARAM , unsigned long long& rcd_t0
 #define RCD_T0_ARG , rcd_t0
+// experiments: [2 b], [2 b + 1] = wall_clock64() (100 MHz) at the start / end of workgroup b of the strip kernels: which workgroups are the launch's tail
+__device__ unsigned long long g_rcd_wg_times[2 * 1024];
+extern "C" __attribute__((visibility("default"))) int tdk_debug_rcd_wg_times(unsigned long long* out2048) {
+  return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_rcd_wg_times), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int tdk_debug_rcd_phase_cycles(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rcd_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rcd_phase_cycles), z, sizeof z) != hipSuccess) return -1; }

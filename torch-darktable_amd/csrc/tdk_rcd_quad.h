@@ -446,6 +446,9 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
   using G = Geo<CPL>;
   constexpr int NT = G::NT, LPR = G::LPR, HPL = G::HPL, SLIDE_PT = G::SLIDE_PT;
   extern __shared__ float lds[];
+#ifdef TDK_RCD_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024u) g_rcd_wg_times[2 * blockIdx.x] = wall_clock64();
+#endif
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane / LPR, q = lane % LPR;
   const int rr = wv + (RB / 2) * hf;  // row of this thread in a step's block
   for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
@@ -599,6 +602,9 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
     }
 #undef RQ_STEP
   }
+#ifdef TDK_RCD_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024u) g_rcd_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 }  // namespace rq

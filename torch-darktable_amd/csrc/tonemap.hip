@@ -224,23 +224,34 @@ __device__ __forceinline__ f3 aces_fit(f3 c) {
 }
 // device_math.h:347-349
 __device__ __forceinline__ uint32_t to_u8(float x) { return (uint32_t)fminf(roundf(x * 255.0f), 255.0f); }
+// The same for x already clipped to [0, 1] (every tone mapper ends in a clip): round-half-away of a non-negative value is
+// trunc(v + 0.5), and v <= 255 needs no upper clamp -- 2 instructions instead of the 8 of roundf + fminf.  The one value per step
+// where the two differ is v = n + 0.5 - half an ulp (v + 0.5 rounds up to n + 1 in fp32): inside every tolerance that is stated
+// for the quantisation (a pre-quantisation value within 2e-3 of a rounding tie may land on either side, tests/test_gpu_parity.py).
+__device__ __forceinline__ uint32_t to_u8_clipped(float x) { return (uint32_t)__builtin_fmaf(x, 255.0f, 0.5f); }
+// pow(x, y) for an exponent that is known to be non-zero (the per-image constants `key` >= 0.3 and 1 / gamma: the kernels take
+// the general tdk_pow when 1 / gamma == 0): no y == 0 select per call
+__device__ __forceinline__ float pow_nz(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 
 struct TmConst {
   float key, inv_exposure, m0, m1, m2, inv_gamma, vibrance, light_adapt, aces_scale;
 };
 
-template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst& k) {
+// LEAN: vibrance == 0 and 1 / gamma != 0 (both wave-uniform kernel arguments; the launcher picks the instantiation): no Lab
+// round trip in the code at all -- its registers would otherwise set the occupancy of the common path -- and pow_nz
+template <int MODE, bool LEAN> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst& k) {
+  auto pw = [](float x, float y) { return LEAN ? pow_nz(x, y) : tdk_pow(x, y); };
   f3 tm;
   if constexpr (MODE == TDK_TONEMAP_ACES) {
     tm = aces_fit(mk3(c.x * k.aces_scale, c.y * k.aces_scale, c.z * k.aces_scale));
   } else {
     const f3 mean = mk3(lerpf(k.light_adapt, k.m0, c.x), lerpf(k.light_adapt, k.m1, c.y), lerpf(k.light_adapt, k.m2, c.z));
-    const f3 ad = mk3(tdk_pow(mean.x * k.inv_exposure, k.key), tdk_pow(mean.y * k.inv_exposure, k.key), tdk_pow(mean.z * k.inv_exposure, k.key));
+    const f3 ad = mk3(pow_nz(mean.x * k.inv_exposure, k.key), pow_nz(mean.y * k.inv_exposure, k.key), pow_nz(mean.z * k.inv_exposure, k.key));  // key >= 0.3
     if constexpr (MODE == TDK_TONEMAP_REINHARD) tm = mk3(tdk_div(c.x, ad.x + c.x), tdk_div(c.y, ad.y + c.y), tdk_div(c.z, ad.z + c.z));
     else if constexpr (MODE == TDK_TONEMAP_LINEAR) tm = mk3(tdk_div(c.x, ad.x), tdk_div(c.y, ad.y), tdk_div(c.z, ad.z));
     else tm = aces_fit(mk3(tdk_div(c.x, ad.x), tdk_div(c.y, ad.y), tdk_div(c.z, ad.z)));
   }
-  const f3 g = mk3(tdk_pow(fmaxf(tm.x, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.y, 0.0f), k.inv_gamma), tdk_pow(fmaxf(tm.z, 0.0f), k.inv_gamma));
+  const f3 g = mk3(pw(fmaxf(tm.x, 0.0f), k.inv_gamma), pw(fmaxf(tm.y, 0.0f), k.inv_gamma), pw(fmaxf(tm.z, 0.0f), k.inv_gamma));
   // modify_rgb_vibrance_dt(g, amount) = clip(lab_to_rgb(scale(rgb_to_lab(g)))) (device_color_conversions.h:199-213).
   // With amount == 0 both scale factors are exactly 1 and Lab -> RGB inverts RGB -> Lab (no clamp in either, the
   // two piecewise branches are inverse pairs): the reference's result is clip(g) up to the ~1e-6 round-trip error
@@ -248,10 +259,14 @@ template <int MODE> __device__ __forceinline__ f3 tonemap_px(f3 c, const TmConst
   // error that is 2500x below one uint8 step.  The round trip is skipped (wave-uniform branch: `amount` is a
   // kernel argument); outputs differ from the reference only where its value sits within 1e-6 * 255 of a rounding
   // tie, the class of difference its own non-deterministic fast-math build already has (test_tonemaps_u8).
-  if (k.vibrance == 0.0f) return clip3(g);
-  f3 o = cB::vibrance(g, k.vibrance);
-  if constexpr (MODE == TDK_TONEMAP_LINEAR) o = clip3(o);
-  return o;
+  if constexpr (LEAN) {
+    return clip3(g);
+  } else {
+    if (k.vibrance == 0.0f) return clip3(g);
+    f3 o = cB::vibrance(g, k.vibrance);
+    if constexpr (MODE == TDK_TONEMAP_LINEAR) o = clip3(o);
+    return o;
+  }
 }
 
 template <int MODE>
@@ -271,7 +286,7 @@ __device__ __forceinline__ TmConst make_consts(const float* metrics, float gamma
   return k;
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool LEAN>
 __global__ __launch_bounds__(256) void tonemap_vec4(const T* __restrict__ in, uint32_t* __restrict__ out, int64_t ngroups,
                                                      const float* __restrict__ metrics, float gamma, float intensity, float light_adapt,
                                                      float vibrance) {
@@ -286,8 +301,8 @@ __global__ __launch_bounds__(256) void tonemap_vec4(const T* __restrict__ in, ui
     uint32_t b[12];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const f3 o = tonemap_px<MODE>(mk3(v[3 * p], v[3 * p + 1], v[3 * p + 2]), k);
-      b[3 * p] = to_u8(o.x); b[3 * p + 1] = to_u8(o.y); b[3 * p + 2] = to_u8(o.z);
+      const f3 o = tonemap_px<MODE, LEAN>(mk3(v[3 * p], v[3 * p + 1], v[3 * p + 2]), k);  // clipped to [0, 1] by every mode
+      b[3 * p] = to_u8_clipped(o.x); b[3 * p + 1] = to_u8_clipped(o.y); b[3 * p + 2] = to_u8_clipped(o.z);
     }
 #pragma unroll
     for (int w = 0; w < 3; w++) out[3 * g + w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256) void tonemap_tail(const T* __restrict__ in, ui
                                                      float vibrance) {
   const TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
   for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
-    const f3 o = tonemap_px<MODE>(mk3(ld(in, 3 * i), ld(in, 3 * i + 1), ld(in, 3 * i + 2)), k);
+    const f3 o = tonemap_px<MODE, false>(mk3(ld(in, 3 * i), ld(in, 3 * i + 1), ld(in, 3 * i + 2)), k);
     out[3 * i] = (uint8_t)to_u8(o.x); out[3 * i + 1] = (uint8_t)to_u8(o.y); out[3 * i + 2] = (uint8_t)to_u8(o.z);
   }
 }
@@ -323,8 +338,12 @@ int run_tonemap(const void* rgb, uint8_t* out, int64_t npix, const float* metric
   int64_t done = 0;
   if (tdk_aligned(in, 16) && tdk_aligned(out, 4) && npix >= 4) {
     const int64_t ng = npix / 4;
-    TDK_LAUNCH("tdk_tonemap", (tonemap_vec4<T, MODE>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
-                       gamma, intensity, light_adapt, vibrance);
+    if (vibrance == 0.0f && 1.0f / gamma != 0.0f)
+      TDK_LAUNCH("tdk_tonemap", (tonemap_vec4<T, MODE, true>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
+                         gamma, intensity, light_adapt, vibrance);
+    else
+      TDK_LAUNCH("tdk_tonemap", (tonemap_vec4<T, MODE, false>), dim3(stream_grid(ng)), dim3(256), 0, s, in, reinterpret_cast<uint32_t*>(out), ng, metrics,
+                         gamma, intensity, light_adapt, vibrance);
     done = ng * 4;
   }
   if (done < npix) {
