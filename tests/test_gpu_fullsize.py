@@ -70,7 +70,7 @@ def test_rcd_12mp_fp16_fast_arithmetic(td, oracle, dev, frame12):
     assert out.dtype == torch.float16 and torch.equal(out, quad)
     m, n = 16, 256
     beyond = touched = 0
-    for y0, x0 in WINDOWS + [(8, 8), (H12 - n - 8, W12 - n - 8)]:
+    for y0, x0 in WINDOWS + [(m, m), (H12 - n - m, W12 - n - m)]:  # (the two corner windows: the crop's own border ring coincides with the frame's)
         ref = oracle.rcd(window(b16, y0, x0, n, m)[:, :, :1], oracle.RGGB)[m:-m, m:-m]
         got = npy(out[y0:y0 + n, x0:x0 + n])
         r16 = ref.astype(np.float16).astype(np.float32)
