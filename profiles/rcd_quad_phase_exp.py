@@ -48,6 +48,7 @@ def main(path):
                 cls[key].append(life[b])
             print(json.dumps({'case': name, 'launch_span_us': us(max(e for _, e in t) - t0), 'last_start_us': us(max(a for a, _ in t) - t0),
                               'lifetime_us': {k: {'n': len(v), 'min': min(v), 'median': sorted(v)[len(v) // 2], 'max': max(v)} for k, v in cls.items()},
+                              'median_lifetime_by_segment_interior_strips': [sorted(life[b] for b in range(nwg) if b // nstrips == sg and 0 < b % nstrips < nstrips - 1)[18] for sg in range(nwg // nstrips)],
                               'end_us_percentiles': [us(sorted(e for _, e in t)[int(q * (nwg - 1))] - t0) for q in (0.1, 0.5, 0.9, 0.99, 1.0)]}))
 
 

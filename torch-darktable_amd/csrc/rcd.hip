@@ -125,10 +125,28 @@ __device__ float diff_1_1(const T* __restrict__ in, int fr, int fc, int w, int h
 
 // Content of the shared VP/HQ buffer at the p/q slot of odd-column site (row, col) when step
 // 4.1 did not write it.
+// flat = row * (w / 2) + (col - 1) / 2 with w even and 0 <= (col - 1) / 2 < w / 2, so flat / w = row >> 1 and
+// flat % w = (row & 1) * (w / 2) + (col - 1) / 2 -- no division (the 64-bit quotient and remainder this replaced were ~400
+// instructions per call for the whole wave, in every step of the strips' border columns: their workgroups were the tail of the
+// launch, profiles/r05/experiments/rcd_wg_times.txt).
 template <typename T>
 __device__ float stale_diff(const T* __restrict__ in, int row, int col, int w, int h, bool p_plane) {
-  const int64_t flat = (int64_t)row * (w / 2) + (col - 1) / 2;
-  return diff_1_1(in, (int)(flat / w), (int)(flat % w), w, h, p_plane);
+  return diff_1_1(in, row >> 1, (row & 1) * (w >> 1) + ((col - 1) >> 1), w, h, p_plane);
+}
+// both planes of one slot: the 13 samples are loaded together (one memory round trip), then the two high-pass values
+template <typename T>
+__device__ void stale_pair(const T* __restrict__ in, int row, int col, int w, int h, float& pv, float& qv) {
+  const int fr = row >> 1, fc = (row & 1) * (w >> 1) + ((col - 1) >> 1);
+  pv = 0.0f; qv = 0.0f;
+  if (fr < 3 || fr > h - 4 || fc < 3 || fc > w - 4) return;
+  const size_t idx = (size_t)fr * w + fc;
+  float v[7], u[7];
+#pragma unroll
+  for (int k = -3; k <= 3; k++) { v[k + 3] = ld(in, idx + (ptrdiff_t)k * w); u[k + 3] = ld(in, idx + k); }
+#pragma unroll
+  for (int k = 0; k < 7; k++) { v[k] = fmaxf(0.0f, v[k]); u[k] = fmaxf(0.0f, u[k]); }
+  pv = sqf(v[0] - 3.0f * v[1] - v[2] + 6.0f * v[3] - v[4] - 3.0f * v[5] + v[6]);
+  qv = sqf(u[0] - 3.0f * u[1] - u[2] + 6.0f * u[3] - u[4] - 3.0f * u[5] + u[6]);
 }
 
 // ---------------------------------------------------------------- border ring [0, 7)
@@ -380,8 +398,7 @@ __device__ __forceinline__ void rcd_phases(const TI* __restrict__ in, T* __restr
           pd = sqf((a[-3 * S - 3] - a[-S - 1] - a[S + 1] + a[3 * S + 3]) - 3.0f * (a[-2 * S - 2] + a[2 * S + 2]) + 6.0f * a[0]);
           qd = sqf((a[-3 * S + 3] - a[-S + 1] - a[S - 1] + a[3 * S - 3]) - 3.0f * (a[-2 * S + 2] + a[2 * S - 2]) + 6.0f * a[0]);
         } else {
-          pd = stale_diff(in, gy, gx, w, h, true);
-          qd = stale_diff(in, gy, gx, w, h, false);
+          stale_pair(in, gy, gx, w, h, pd, qd);
         }
       }
       pB[r * S + c] = pd;

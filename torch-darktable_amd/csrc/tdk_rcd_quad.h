@@ -157,7 +157,7 @@ __device__ __forceinline__ void q_step_2_1_1_1_4_1(const Lane& t, int gyb, const
         const int gx = t.gxq + ci;
         const bool inside = gy >= 0 && gy < t.h && gx >= 0 && gx < t.w, ranged = gy >= 3 && gy <= t.h - 4 && gx >= 3 && gx <= t.w - 4;
         if (__builtin_amdgcn_ballot_w64(inside && !ranged) != 0) {
-          if (inside && !ranged) { pv[k] = stale_diff(in, gy, gx, t.w, t.h, true); qv[k] = stale_diff(in, gy, gx, t.w, t.h, false); }
+          if (inside && !ranged) stale_pair(in, gy, gx, t.w, t.h, pv[k], qv[k]);
         }
         const lmask m = __builtin_amdgcn_ballot_w64(inside);
         pv[k] = keep(m, pv[k]);

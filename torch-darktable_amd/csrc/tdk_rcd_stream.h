@@ -225,7 +225,7 @@ __device__ __forceinline__ void step_2_1_1_1_4_1(float* __restrict__ b128, float
       // rcd.hip); outside the frame: 0
       const lmask inside = rule(rv.rimg41, cv.img), stale = inside & ~rule(rv.r11, cv.c3[1]);
       if (stale != 0) {
-        if ((stale >> (threadIdx.x & 63)) & 1) { pv = stale_diff(in, gy41, gx_odd, w, h, true); qv = stale_diff(in, gy41, gx_odd, w, h, false); }
+        if ((stale >> (threadIdx.x & 63)) & 1) stale_pair(in, gy41, gx_odd, w, h, pv, qv);
       }
       pv = keep(inside, pv);
       qv = keep(inside, qv);
