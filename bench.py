@@ -360,6 +360,15 @@ def build_pipeline(td, dev, w, h, storage, workload, chain='lab'):
     rcd = td.RCD(dev, (w, h), td.BayerPattern.RGGB)
     if workload == 'rcd':
         return dtype, lambda bayer: rcd.process(bayer)
+    if os.environ.get('TDK_BENCH_RCD_STANDALONE'):  # A/B knob (profiles/): the stand-alone strips (rs::rcd_stream) also with frames in flight
+        from torch_darktable.torch_darktable_extension import concurrent_frames
+
+        class _Plain:
+            def process(self, x):
+                with concurrent_frames(False):
+                    return rcd_.process(x)
+
+        rcd_, rcd = rcd, _Plain()
     wiener = td.Wiener(dev, (w, h), overlap_factor=4, tile_size=32)
     bilateral = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
     params = td.TonemapParameters(gamma=0.75, intensity=2.0, light_adapt=1.0, vibrance=0.0)

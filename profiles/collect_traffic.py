@@ -35,6 +35,9 @@ KERNELS = {
     # y-streaming tile kernel (K = 32, ov = 4): 16-B staging loads of in-frame groups, 64 consecutive bytes per 4 lanes
     'wiener_ystream': ('tdk_wiener(tiles)', True),
     'wiener_finish_modify': ('tdk_wiener(finish+modify)', True),
+    'wiener_finish_lab': ('tdk_wiener(finish+lab)', True),     # Lab hand-over chain: slabs + (a, b) in, lightness out
+    'lum_lab_extract': ('tdk_compute_luminance(lab)', True),   # RGB in, log-lightness + (a, b) planes out
+    'slice_lab_kernel': ('tdk_bilateral(slice+lab)', False),
     'wiener_finish<': ('tdk_wiener(finish)', True),
     'rcd_interior': ('tdk_rcd', False),
     # column strips: one 4-B (fp16) / 8-B (fp32) sample pair per lane and step, 12-B / 24-B pixel pairs out

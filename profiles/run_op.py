@@ -43,6 +43,7 @@ def main():
     params = td.TonemapParameters(0.75, 2.0, 1.0, 0.0)
     metrics = td.compute_image_metrics([rgb], 8)
     lum_plane = torch.empty((h, w), dtype=torch.float32, device=dev)
+    ab_plane = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
     acc = td.tonemap.MetricsAccumulator(dev, stride=8)
     torch.cuda.synchronize()
     for _ in range(a.iters):
@@ -63,6 +64,12 @@ def main():
         elif a.op == 'luminance':
             td.modify_luminance(rgb, td.compute_luminance(rgb))
         elif a.op == 'isp':  # the chain bench.py times (with its stage hand-overs; the kernels it runs with frames on several streams)
+            with td.torch_darktable_extension.concurrent_frames():
+                x = rcd.process(bayer)
+            wiener.process_log_luminance_lab(x, 0.075, luminance_out=lum_plane, chroma_out=ab_plane)
+            x = bil.process_lab(lum_plane, ab_plane, 0.4, out_dtype=x.dtype, metrics=acc)
+            td.reinhard_tonemap(x, acc.finish(), params)
+        elif a.op == 'isp_rgb':  # the same chain with the intermediate RGB image materialised (bench.py --chain rgb)
             with td.torch_darktable_extension.concurrent_frames():
                 x = rcd.process(bayer)
             x = wiener.process_log_luminance(x, 0.075, luminance_out=lum_plane)

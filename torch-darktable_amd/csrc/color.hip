@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void lum_extract_tail(const TR* __restrict__ r
 template <typename TR, int VEC>
 __global__ __launch_bounds__(256) void lum_lab_extract(const TR* __restrict__ rgb, float* __restrict__ loglum, float* __restrict__ ab, int64_t first,
                                                        int64_t ngroups, float eps) {
+  TDK_STREAMING_KERNEL_PROLOGUE();
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
     float v[3 * VEC], l[VEC], c2[2 * VEC];
     if constexpr (VEC == 4) rgb4_io<TR>::load(rgb, g, v);

@@ -23,6 +23,33 @@
 #undef TDK_BIL_TIMING
 #endif
 
+// Wave priority of the short streaming kernels (luminance extraction, Wiener finish, metrics, tone map).  With several frames in
+// flight their waves are always the YOUNGEST on a SIMD, and the issue arbiter serves the oldest wave first: next to the long-lived
+// waves of the RCD / Wiener / bilateral tile kernels a tone-map launch takes 3.7 x its stand-alone time
+// (profiles/r05/bench_isp_plain.json: kernel_ms_per_frame_streams).  s_setprio raises the wave's own priority (0 .. 3).
+#ifndef TDK_STREAMING_PRIO
+#define TDK_STREAMING_PRIO 0
+#endif
+// Rotating wave priority inside the long-running tile kernels.  All their workgroups are resident at once (2 or 3 per CU), the
+// issue arbiter serves the OLDEST wave of a SIMD first, and so the first workgroup of every CU runs at full speed while the later
+// ones take what is left and then finish alone, one wave per SIMD, at half the issue rate (profiles/r05/experiments/
+// wg_lifetimes.txt: Wiener strips end at 115 / 165 us, RCD strips at 73 / 97 / 115 us).  tdk_rotate_prio(step) makes wave slot s
+// the favoured one in every N-th step, so that the waves of a SIMD advance together and keep each other's stalls covered to the end.
+#ifndef TDK_FAIR_PRIO
+#define TDK_FAIR_PRIO 0
+#endif
+__device__ __forceinline__ int tdk_wave_slot() {  // HW_REG_HW_ID (4), WAVE_ID = bits 3:0: the wave's slot on its SIMD
+  return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+}
+template <int N> __device__ __forceinline__ void tdk_rotate_prio(int step, int slot) {
+  if (TDK_FAIR_PRIO) {
+    if ((step + slot) % N == 0) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+#define TDK_STREAMING_KERNEL_PROLOGUE() do { if (TDK_STREAMING_PRIO > 0) __builtin_amdgcn_s_setprio(TDK_STREAMING_PRIO); } while (0)
+
 // ---------------------------------------------------------------- host side: status + launch checks
 void tdk_set_error(const char* fmt, ...);
 int tdk_device_cus();  // compute units of the current device (cached)

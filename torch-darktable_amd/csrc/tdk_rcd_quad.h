@@ -514,7 +514,9 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
 #ifdef TDK_RCD_TIMING
   unsigned long long rq_t0 = clock64();
 #endif
+  const int wslot = TDK_FAIR_PRIO ? tdk_wave_slot() : 0;
   for (int b = 0; b < nsteps; b++) {
+    tdk_rotate_prio<3>(b, wslot);
     // ---- slide: every plane moves up by 8 rows (its live rows; the rest is rewritten in this step)
     if (b > 0) {
       // (named registers, not an array: across the fence of the barrier an array would be kept in scratch memory)

@@ -30,6 +30,7 @@ namespace ys {
 #if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
 // experiments: clock64() deltas per phase and wave of one workgroup, summed over its steps (profiles/wiener_ablate_exp.py)
 __device__ unsigned long long g_ys_phase_cycles[4][8];
+__device__ unsigned long long g_ys_wg_times[2 * 2048];  // [2 b], [2 b + 1]: wall_clock64() (100 MHz) at the start / end of workgroup b
 #define YS_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ys_acc[k] += t_ - ys_t0; ys_t0 = t_; } while (0)  // wave-uniform: lives in SGPRs
 #else
 #define YS_MARK(k)
@@ -232,6 +233,9 @@ template <typename T, bool LUM>
 __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ img, float* __restrict__ slabs, int W, int H, int C, int chan0, int vec_ok, Geom g,
                                                          const float* __restrict__ sigmas, YParams yp, size_t plane_stride, float lum_eps) {
   __shared__ Smem sm;
+#if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+  if (threadIdx.x == 0 && blockIdx.x < 2048u) g_ys_wg_times[2 * blockIdx.x] = wall_clock64();
+#endif
   int chan = chan0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ngroups = g.ngx * g.ngy;
@@ -312,7 +316,9 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
   // The hand-over buffers are single: fwd / meta are written in A and read in B, inv and the staging block in B and A.
   const int NJ = (NB + 4) / 2 + 2;
   const int rblk = wave & 1, sblk = wave >> 1;  // the block of the pair this wave takes in its row stage / stages
+  const int wslot = TDK_FAIR_PRIO ? tdk_wave_slot() : 0;
   for (int it = 0; it < NJ; it++) {
+    tdk_rotate_prio<2>(it, wslot);
     // ---- phase A
     if (wave >= 2) {
       // inverse row stage: the block emitted in the previous iteration (slab block e)
@@ -545,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void wiener_ystream(const T* __restrict__ i
 #if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
   if (lane == 0 && blockIdx.x == 200)
     for (int k = 0; k < 7; k++) g_ys_phase_cycles[wave][k] += ys_acc[k];
+  if (threadIdx.x == 0 && blockIdx.x < 2048u) g_ys_wg_times[2 * blockIdx.x + 1] = wall_clock64();
 #endif
 }
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ img,
                                                       float min_gray, const float* __restrict__ bounds, float* __restrict__ acc, float* __restrict__ finish_to) {
   __shared__ float part[4][6];
   __shared__ int last_block;
+  TDK_STREAMING_KERNEL_PROLOGUE();
   const int64_t n = (int64_t)sw * sh;
   const float b0 = bounds[0];
   const float range = bounds[1] - b0 + 1e-6f;
@@ -290,6 +291,7 @@ template <typename T, int MODE, bool LEAN>
 __global__ __launch_bounds__(256) void tonemap_vec4(const T* __restrict__ in, uint32_t* __restrict__ out, int64_t ngroups,
                                                      const float* __restrict__ metrics, float gamma, float intensity, float light_adapt,
                                                      float vibrance) {
+  TDK_STREAMING_KERNEL_PROLOGUE();
   TmConst k = make_consts<MODE>(metrics, gamma, intensity, light_adapt, vibrance);
   // The per-image constants are wave-uniform, so hipcc keeps them in SGPRs -- and a VALU instruction with an SGPR source
   // issues at half rate on gfx950 (4.4 instead of 2.4 cycles, tests/hip_unit/valu_issue_bench.hip); they are used ~20 times

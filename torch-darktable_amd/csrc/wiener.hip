@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) void wiener_finish_modify(const float* __restr
 template <int VEC>
 __global__ __launch_bounds__(256) void wiener_finish_lab(const float* __restrict__ slabs, float* __restrict__ ab, float* __restrict__ lum_out, int W, int H,
                                                          Geom g, WParams prm) {
+  TDK_STREAMING_KERNEL_PROLOGUE();
   const int u0 = -g.jmin * g.s;
   const size_t slab_sz = (size_t)g.RSXP * g.RSY;
   const int ngroup = W / VEC;
@@ -954,6 +955,9 @@ int launch_log_luminance_lab(const void* rgb_in, void* workspace, int W, int H, 
 }  // namespace
 
 #if defined(TDK_EXPERIMENTS) && defined(TDK_YS_TIMING)
+TDK_EXPORT int tdk_debug_ys_wg_times(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(ys::g_ys_wg_times), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -1;
+}
 TDK_EXPORT int tdk_debug_ys_phase_cycles(unsigned long long* out32, int reset) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ys::g_ys_phase_cycles), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ys::g_ys_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
