@@ -42,13 +42,25 @@ def main(path):
             us = lambda ticks: round(ticks / 100.0, 1)
             life = [us(e - a) for a, e in t]
             cls = {'interior': [], 'border strip (0, 37)': [], 'first / last segment': []}
+            nsegs = nwg // nstrips
+
+            def strip_seg(b):  # rs::strip_map (tdk_rcd_stream.h): border strips first, then the first / last segments, then the rest
+                ni, e1, e2 = nstrips - 2, 2 * nsegs, 2 * (nstrips - 2)
+                if b < e1:
+                    return (nstrips - 1 if b & 1 else 0), b >> 1
+                if b < e1 + e2:
+                    i = b - e1
+                    return 1 + (i >> 1), (nsegs - 1 if i & 1 else 0)
+                i = b - e1 - e2
+                return 1 + i % ni, 1 + i // ni
+
             for b in range(nwg):
-                strip, seg = b % nstrips, b // nstrips
+                strip, seg = strip_seg(b)
                 key = 'border strip (0, 37)' if strip in (0, nstrips - 1) else ('first / last segment' if seg in (0, nwg // nstrips - 1) else 'interior')
                 cls[key].append(life[b])
             print(json.dumps({'case': name, 'launch_span_us': us(max(e for _, e in t) - t0), 'last_start_us': us(max(a for a, _ in t) - t0),
                               'lifetime_us': {k: {'n': len(v), 'min': min(v), 'median': sorted(v)[len(v) // 2], 'max': max(v)} for k, v in cls.items()},
-                              'median_lifetime_by_segment_interior_strips': [sorted(life[b] for b in range(nwg) if b // nstrips == sg and 0 < b % nstrips < nstrips - 1)[18] for sg in range(nwg // nstrips)],
+                              'median_lifetime_by_launch_order_256s': [sorted(life[k:k + 256])[len(life[k:k + 256]) // 2] for k in range(0, nwg, 256)],
                               'end_us_percentiles': [us(sorted(e for _, e in t)[int(q * (nwg - 1))] - t0) for q in (0.1, 0.5, 0.9, 0.99, 1.0)]}))
 
 

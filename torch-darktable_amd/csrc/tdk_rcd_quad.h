@@ -451,11 +451,14 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
 #endif
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane / LPR, q = lane % LPR;
   const int rr = wv + (RB / 2) * hf;  // row of this thread in a step's block
-  for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
-    ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
-    __syncthreads();
+  const StripMap sm_ = strip_map((int)blockIdx.x, nstrips, (int)gridDim.x / nstrips, 2 * (nbx + nby));
+  if ((int)blockIdx.x >= sm_.ring_first && (int)blockIdx.x < sm_.ring_first + sm_.ring_count) {  // workgroup-uniform
+    for (int b = (int)blockIdx.x - sm_.ring_first; b < 2 * (nbx + nby); b += sm_.ring_count) {
+      ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
+      __syncthreads();
+    }
   }
-  const int strip = (int)blockIdx.x % nstrips, seg = (int)blockIdx.x / nstrips;
+  const int strip = sm_.strip, seg = sm_.seg;
   const int xs = min(strip * TWS, w - TWS), ys = min(seg * seg_rows, h - seg_rows);
   const int gx0 = xs - HALO, gy0 = ys - HALO;  // frame position of window column 0 / row 0; both even
   const int nsteps = (seg_rows + 2 * HALO + RB - 1) / RB;

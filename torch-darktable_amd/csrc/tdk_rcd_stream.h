@@ -413,6 +413,35 @@ __device__ __forceinline__ void step_5_2_out(float* __restrict__ b128, float* __
   else store(oth, own, other, native);
 }
 
+// Workgroup number -> (strip, segment), and which workgroups stage the ring pieces.
+// Every workgroup of the launch is resident from the start (<= 3 per CU), and the issue arbiter serves the OLDEST wave of a SIMD
+// first: the k-th workgroup of a CU in launch order ends in the k-th of three classes (73 / 97 / 115 us at 12 MP,
+// profiles/r05/experiments/wg_lifetimes.txt), and the launch ends with its slowest workgroup.  The slow ones are known in advance
+// -- the two border strips (every step runs the variant with border rules and stale slots: +25 %) and the first / last segment of
+// the other strips (border rows) -- so they get the LOWEST numbers and with them the fast class; the ring pieces (a few us each)
+// go to workgroups behind them, two per workgroup, so that none of them lands in the last class.
+struct StripMap {
+  int strip, seg;
+  int ring_first, ring_count;  // workgroups [ring_first, ring_first + ring_count) stage the ring pieces, piece p on ring_first + p % ring_count
+};
+__device__ __forceinline__ StripMap strip_map(int b, int nstrips, int nsegs, int npieces) {
+  StripMap m;
+  const int nwg = nstrips * nsegs;
+  if (nstrips < 3 || nsegs < 3) {  // small frames: plain order
+    m.strip = b % nstrips; m.seg = b / nstrips;
+    m.ring_first = 0; m.ring_count = nwg;
+    return m;
+  }
+  const int ni = nstrips - 2, e1 = 2 * nsegs, e2 = 2 * ni;
+  if (b < e1) { m.strip = (b & 1) ? nstrips - 1 : 0; m.seg = b >> 1; }
+  else if (b < e1 + e2) { const int i = b - e1; m.strip = 1 + (i >> 1); m.seg = (i & 1) ? nsegs - 1 : 0; }
+  else { const int i = b - e1 - e2; m.seg = 1 + i / ni; m.strip = 1 + i - (m.seg - 1) * ni; }
+  m.ring_first = e1 + e2;
+  const int rest = nwg - m.ring_first, want = (npieces + 1) / 2;
+  m.ring_count = rest < want ? rest : (want > 0 ? want : 1);
+  return m;
+}
+
 template <typename TI> struct Pair;
 template <> struct Pair<float> {
   float2 v;
@@ -444,12 +473,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
   // the [0, 7) border ring (independent of the strips: disjoint output pixels, input read-only): one piece per workgroup until
   // the pieces run out, staged through the plane area
-  for (int b = (int)blockIdx.x; b < 2 * (nbx + nby); b += (int)gridDim.x) {
-    ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
-    __syncthreads();
+  const StripMap sm_ = strip_map((int)blockIdx.x, nstrips, (int)gridDim.x / nstrips, 2 * (nbx + nby));
+  if ((int)blockIdx.x >= sm_.ring_first && (int)blockIdx.x < sm_.ring_first + sm_.ring_count) {  // workgroup-uniform
+    for (int b = (int)blockIdx.x - sm_.ring_first; b < 2 * (nbx + nby); b += sm_.ring_count) {
+      ring_piece(in, out, w, h, pattern, nbx, nby, b, lds, NT);
+      __syncthreads();
+    }
   }
 
-  const int strip = (int)blockIdx.x % nstrips, seg = (int)blockIdx.x / nstrips;
+  const int strip = sm_.strip, seg = sm_.seg;
   // the last strip / segment is moved back so that it ends at the frame's edge (it recomputes what its neighbour also writes)
   const int xs = min(strip * TWS, w - TWS), ys = min(seg * seg_rows, h - seg_rows);
   const int gx0 = xs - HALO, gy0 = ys - HALO;  // frame position of window column 0 / row 0; both even
