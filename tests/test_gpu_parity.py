@@ -361,6 +361,28 @@ def test_postprocess_bit_exact_paths(td, oracle, dev, scene, cfg):
     assert np.array_equal(got, oracle.postprocess(rgb, oracle.RGGB, **cfg))
 
 
+@pytest.mark.parametrize('size', [(96, 256), (50, 132), (33, 64), (16, 68), (131, 320)])
+@pytest.mark.parametrize('cfg', [dict(color_smoothing_passes=3, green_eq_local=True), dict(color_smoothing_passes=4), dict(color_smoothing_passes=1),
+                                 dict(green_eq_local=True, green_eq_threshold=4.0), dict(color_smoothing_passes=7, green_eq_local=True)])
+def test_postprocess_vector_paths_bit_exact(td, oracle, dev, scene, size, cfg):
+    """Widths that are multiples of 4 take the 16-byte staging / store paths of the smoothing and local green-equilibration kernels
+    (partial tiles on the right and bottom, tiles narrower than 64, a single tile row); a scene with negative and > 1 samples
+    exercises the clamps."""
+    h, w = size
+    rgb = oracle.rcd(oracle.mosaic(scene(h, w, 31), oracle.RGGB), oracle.RGGB)
+    rgb[5:9, 7:30] -= 0.3
+    rgb[h // 2:h // 2 + 3, :] *= 1.7
+    ws = td.PostProcess(dev, (w, h), td.BayerPattern.RGGB, **cfg)
+    got = npy(ws.process(gpu(rgb, dev)))
+    ref = oracle.postprocess(rgb, oracle.RGGB, **cfg)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f'{len(bad)} mismatches, first at {bad[:5].tolist()}'
+    # an input view that is not 16-byte aligned takes the scalar loads; same bits
+    pad = torch.zeros(h * w * 3 + 1, device=dev)
+    pad[1:] = gpu(rgb, dev).reshape(-1)
+    assert np.array_equal(npy(ws.process(pad[1:].view(h, w, 3))), ref)
+
+
 def test_postprocess_global_green_eq(td, oracle, dev, scene):
     h, w = 90, 134
     rgb = oracle.rcd(oracle.mosaic(scene(h, w, 17), oracle.RGGB), oracle.RGGB)

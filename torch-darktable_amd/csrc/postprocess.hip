@@ -34,88 +34,152 @@ __device__ __forceinline__ float median9(float s0, float s1, float s2, float s3,
   return med3f(lo, mid, hi);
 }
 
-constexpr int STW = 64, STH = 16, SNT = 512;  // tile and threads per workgroup: 35 KB of LDS -> 4 workgroups x 8 waves per CU
-constexpr int SPX = STW * STH / SNT;         // pixels per thread in the last pass (2)
+constexpr int STW = 64, STH = 16, SNT = 512;  // tile and threads per workgroup: 36 KB of LDS -> 4 workgroups x 8 waves per CU
 
 // Up to FMAXP smoothing passes in ONE kernel: the tile + P-px halo is read once, the (R-G, B-G)
 // planes ping-pong in LDS while the valid region shrinks by one pixel per pass, and only the last
 // pass touches HBM again -- 24 B/px of traffic instead of 24 B/px per pass.  Every pass computes
 // exactly one reference pass (postprocess.cu:24-78; differences are zero outside the image at every pass).
+//
+// Round 5 (was 115 us for three passes at 12 MP, a third of its LDS cycles in bank conflicts):
+//  * staging: one thread = 4 consecutive pixels of a row = three 16-B loads (the region is taken from the 4-aligned column
+//    x0 - 4), instead of three 4-byte loads 12 bytes apart per pixel; the planes go to LDS as 16-B row groups;
+//  * passes: a thread walks a short vertical run of one column with the 3 x 3 window in registers -- 3 new samples per plane
+//    and pixel instead of 9, and the lanes of a wave sit on consecutive columns of one row: unit-stride, conflict-free
+//    (two pixels side by side per thread made every read a stride-2 access);
+//  * last pass: results go through the two dead planes as an interleaved RGB tile and leave as 16-B stores.
 constexpr int FMAXP = 4;
-constexpr int FLW = STW + 2 * FMAXP, FLH = STH + 2 * FMAXP, FLS = FLW + 1;
+constexpr int FCO = 4;                 // LDS column of image column x0 (>= FMAXP, a multiple of 4: staged groups are 16-B aligned)
+constexpr int FLW = STW + 2 * FCO;     // 72 staged columns
+constexpr int FLH = STH + 2 * FMAXP;   // 24 rows; LDS row of image row y0 = FMAXP
+constexpr int FLS = 76;                // row stride: a multiple of 4
+constexpr int FPL = (FLH + 2) * FLS;   // one plane (+2 rows: the last run of a pass reads up to two rows past the region; never used)
+static_assert(4 * 5 * FPL * sizeof(float) <= 160 * 1024, "four workgroups per CU");
+constexpr int FGR = FLW / 4;           // 18 four-pixel groups per staged row
+static_assert(FGR * FLH <= SNT, "staging: one group per thread");
+static_assert(2 * FPL >= STH * STW * 3, "the last pass's RGB tile fits two planes");
 
-__global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height, int vec_ok,
+// vec_in / vec_ok: width % 4 == 0 and `in` / `out` 16-byte aligned
+__global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height, int vec_in, int vec_ok,
                                                               int passes) {
-  __shared__ float G[FLH * FLS], DR[2][FLH * FLS], DB[2][FLH * FLS];
+  __shared__ __align__(16) float lds[5 * FPL];  // G | DR0 | DB0 | DR1 | DB1
+  float* G = lds;
+  auto DR = [&](int k) { return lds + (1 + 2 * k) * FPL; };
+  auto DB = [&](int k) { return lds + (2 + 2 * k) * FPL; };
   const int P = passes;  // 1..FMAXP
   const int x0 = blockIdx.x * STW, y0 = blockIdx.y * STH;
-  const int rw = STW + 2 * P, rh = STH + 2 * P;
-  // i / n by float reciprocal: exact for i < 2^20, n < 2^10 ((i + 0.5) / n is >= 0.5 / n from an integer)
-  const float inv_rw = 1.0f / (float)rw;
-  for (int i = threadIdx.x; i < rw * rh; i += SNT) {
-    const int r = (int)(((float)i + 0.5f) * inv_rw), c = i - r * rw;
-    const int gx = x0 - P + c, gy = y0 - P + r;
-    float g = 0.0f, a = 0.0f, b = 0.0f;
-    if (gx >= 0 && gy >= 0 && gx < width && gy < height) {
-      const float* p = in + ((size_t)gy * width + gx) * 3;
-      g = p[1];
-      a = p[0] - g;
-      b = p[2] - g;
+  const int tid = threadIdx.x;
+  // ---- staging: rows y0 - P .. y0 + STH + P - 1, columns x0 - FCO .. x0 + STW + FCO - 1
+  {
+    const int rh = STH + 2 * P;
+    if (tid < FGR * rh) {
+      const int r = tid / FGR, g4 = tid - r * FGR;
+      const int gy = y0 - P + r, gx = x0 - FCO + 4 * g4;
+      float g[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (gy >= 0 && gy < height) {
+        if (vec_in && gx >= 0 && gx + 4 <= width) {  // width % 4 == 0 and a 16-B aligned image: the group is three aligned 16-B loads
+          float v[12];
+          rgb4_io<float>::load(in, ((size_t)gy * width + gx) >> 2, v);
+#pragma unroll
+          for (int k = 0; k < 4; k++) { g[k] = v[3 * k + 1]; a[k] = v[3 * k] - g[k]; b[k] = v[3 * k + 2] - g[k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (gx + k >= 0 && gx + k < width) {
+              const float* p = in + ((size_t)gy * width + gx + k) * 3;
+              g[k] = p[1]; a[k] = p[0] - g[k]; b[k] = p[2] - g[k];
+            }
+        }
+      }
+      const int q = (FMAXP - P + r) * FLS + 4 * g4;
+      const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(G + q) = make_float4(g[0], g[1], g[2], g[3]);
+      *reinterpret_cast<float4*>(DR(0) + q) = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4*>(DB(0) + q) = make_float4(b[0], b[1], b[2], b[3]);
+      *reinterpret_cast<float4*>(DR(1) + q) = z;  // out-of-image sites stay zero in both buffers
+      *reinterpret_cast<float4*>(DB(1) + q) = z;
     }
-    const int q = r * FLS + c;
-    G[q] = g;
-    DR[0][q] = a; DB[0][q] = b;
-    DR[1][q] = 0.0f; DB[1][q] = 0.0f;  // out-of-image sites stay zero in both buffers
   }
   __syncthreads();
   int cur = 0;
+  // ---- all passes but the last: region shrinks by one pixel per pass; a thread = one column, RS consecutive rows
   for (int p = 0; p + 1 < P; p++) {
+    constexpr int RS = 3;
     const int m = P - 1 - p;  // halo still needed after this pass
-    const int cw = STW + 2 * m, ch = STH + 2 * m, off = P - m;
-    const float* dr = DR[cur];
-    const float* db = DB[cur];
-    const float inv_cw = 1.0f / (float)cw;
-    for (int i = threadIdx.x; i < cw * ch; i += SNT) {
-      const int rr = (int)(((float)i + 0.5f) * inv_cw), r = rr + off, c = i - rr * cw + off;
-      const int gx = x0 - P + c, gy = y0 - P + r;
-      if (gx < 0 || gy < 0 || gx >= width || gy >= height) continue;
-      const int q = r * FLS + c;
-      const float rm = median9(dr[q - FLS - 1], dr[q - FLS], dr[q - FLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + FLS - 1], dr[q + FLS], dr[q + FLS + 1]);
-      const float bm = median9(db[q - FLS - 1], db[q - FLS], db[q - FLS + 1], db[q - 1], db[q], db[q + 1], db[q + FLS - 1], db[q + FLS], db[q + FLS + 1]);
-      const float g = G[q];
-      const float nr = fmaxf(fmaxf(rm + g, 0.0f), 0.0f), ng = fmaxf(g, 0.0f), nb = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
-      G[q] = ng;  // only this thread reads G[q]
-      DR[cur ^ 1][q] = nr - ng;
-      DB[cur ^ 1][q] = nb - ng;
+    const int cw = STW + 2 * m, ch = STH + 2 * m, nseg = (ch + RS - 1) / RS;
+    const float* dr = DR(cur);
+    const float* db = DB(cur);
+    float* dro = DR(cur ^ 1);
+    float* dbo = DB(cur ^ 1);
+    const float inv_cw = 1.0f / (float)cw;  // i / n by float reciprocal: exact for i < 2^20, n < 2^10
+    for (int i = tid; i < cw * nseg; i += SNT) {
+      const int sg = (int)(((float)i + 0.5f) * inv_cw), col = i - sg * cw;
+      const int c = FCO - m + col, r0 = FMAXP - m + RS * sg;
+      const int gx = x0 - FCO + c;
+      if (gx < 0 || gx >= width) continue;
+      const float* pr = dr + (r0 - 1) * FLS + c;
+      const float* pb = db + (r0 - 1) * FLS + c;
+      float wr[RS + 2][3], wb[RS + 2][3];
+#pragma unroll
+      for (int j = 0; j < RS + 2; j++) {  // (rows beyond the region are inside the plane: FMAXP rows / FCO columns of margin)
+#pragma unroll
+        for (int d = 0; d < 3; d++) { wr[j][d] = pr[j * FLS + d - 1]; wb[j][d] = pb[j * FLS + d - 1]; }
+      }
+#pragma unroll
+      for (int k = 0; k < RS; k++) {
+        const int r = r0 + k, gy = y0 - FMAXP + r;
+        if (RS * sg + k >= ch || gy < 0 || gy >= height) continue;
+        const int q = r * FLS + c;
+        const float rm = median9(wr[k][0], wr[k][1], wr[k][2], wr[k + 1][0], wr[k + 1][1], wr[k + 1][2], wr[k + 2][0], wr[k + 2][1], wr[k + 2][2]);
+        const float bm = median9(wb[k][0], wb[k][1], wb[k][2], wb[k + 1][0], wb[k + 1][1], wb[k + 1][2], wb[k + 2][0], wb[k + 2][1], wb[k + 2][2]);
+        const float g = G[q];
+        const float nr = fmaxf(fmaxf(rm + g, 0.0f), 0.0f), ng = fmaxf(g, 0.0f), nb = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
+        G[q] = ng;  // only this thread reads G[q]
+        dro[q] = nr - ng;
+        dbo[q] = nb - ng;
+      }
     }
     cur ^= 1;
     __syncthreads();
   }
-  // last pass: SPX consecutive pixels per thread straight to HBM
-  const float* dr = DR[cur];
-  const float* db = DB[cur];
-  constexpr int TPR = STW / SPX;  // threads per tile row
-  const int lx = (threadIdx.x % TPR) * SPX, ly = threadIdx.x / TPR;
-  const int x = x0 + lx, y = y0 + ly;
-  if (x >= width || y >= height) return;
-  float px[3 * SPX];
+  // ---- last pass: wave = two tile rows, lane = column; the RGB tile is assembled in the two dead planes
+  {
+    const float* dr = DR(cur);
+    const float* db = DB(cur);
+    float* tile = DR(cur ^ 1);  // DR(k), DB(k) are adjacent: 2 FPL floats >= 16 x 192
+    const int col = tid & 63, sg = tid >> 6;
+    const int c = FCO + col, r0 = FMAXP + 2 * sg;
+    const float* pr = dr + (r0 - 1) * FLS + c;
+    const float* pb = db + (r0 - 1) * FLS + c;
+    float wr[4][3], wb[4][3];
 #pragma unroll
-  for (int k = 0; k < SPX; k++) {
-    const int q = (ly + P) * FLS + (lx + k + P);
-    const float rm = median9(dr[q - FLS - 1], dr[q - FLS], dr[q - FLS + 1], dr[q - 1], dr[q], dr[q + 1], dr[q + FLS - 1], dr[q + FLS], dr[q + FLS + 1]);
-    const float bm = median9(db[q - FLS - 1], db[q - FLS], db[q - FLS + 1], db[q - 1], db[q], db[q + 1], db[q + FLS - 1], db[q + FLS], db[q + FLS + 1]);
-    const float g = G[q];
-    px[3 * k] = fmaxf(fmaxf(rm + g, 0.0f), 0.0f);
-    px[3 * k + 1] = fmaxf(g, 0.0f);
-    px[3 * k + 2] = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
-  }
-  float* o = out + ((size_t)y * width + x) * 3;
-  if (vec_ok) {  // width % 4 == 0, 16-B aligned image: a pixel pair starts on an 8-B boundary
-    static_assert(SPX == 2, "vector store below writes 2 pixels");
-    float2* o2 = reinterpret_cast<float2*>(o);
-    o2[0] = make_float2(px[0], px[1]); o2[1] = make_float2(px[2], px[3]); o2[2] = make_float2(px[4], px[5]);
-  } else {
-    for (int k = 0; k < SPX && x + k < width; k++) { o[3 * k] = px[3 * k]; o[3 * k + 1] = px[3 * k + 1]; o[3 * k + 2] = px[3 * k + 2]; }
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) { wr[j][d] = pr[j * FLS + d - 1]; wb[j][d] = pb[j * FLS + d - 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const float rm = median9(wr[k][0], wr[k][1], wr[k][2], wr[k + 1][0], wr[k + 1][1], wr[k + 1][2], wr[k + 2][0], wr[k + 2][1], wr[k + 2][2]);
+      const float bm = median9(wb[k][0], wb[k][1], wb[k][2], wb[k + 1][0], wb[k + 1][1], wb[k + 1][2], wb[k + 2][0], wb[k + 2][1], wb[k + 2][2]);
+      const float g = G[(r0 + k) * FLS + c];
+      float* t = tile + (2 * sg + k) * (3 * STW) + 3 * col;
+      t[0] = fmaxf(fmaxf(rm + g, 0.0f), 0.0f);
+      t[1] = fmaxf(g, 0.0f);
+      t[2] = fmaxf(fmaxf(bm + g, 0.0f), 0.0f);
+    }
+    __syncthreads();
+    const int cols = min(STW, width - x0);  // pixels of a tile row inside the image
+    if (vec_ok && cols == STW) {            // whole 16-B groups: 48 per row
+      for (int i = tid; i < STH * (3 * STW / 4); i += SNT) {
+        const int r = i / (3 * STW / 4), k = i - r * (3 * STW / 4);
+        if (y0 + r < height) *reinterpret_cast<float4*>(out + ((size_t)(y0 + r) * width + x0) * 3 + 4 * k) = *reinterpret_cast<const float4*>(tile + r * (3 * STW) + 4 * k);
+      }
+    } else {
+      for (int i = tid; i < STH * 3 * STW; i += SNT) {
+        const int r = i / (3 * STW), f = i - r * (3 * STW);
+        if (y0 + r < height && f < 3 * cols) out[((size_t)(y0 + r) * width + x0) * 3 + f] = tile[r * (3 * STW) + f];
+      }
+    }
   }
 }
 
@@ -193,37 +257,102 @@ __global__ __launch_bounds__(256) void green_apply_kernel(const float* __restric
 // green channel of the tile + 2-px halo is staged in LDS once (zero outside the image, as the
 // reference's guarded loads), so the eight neighbour greens of a G2 site are LDS reads instead of
 // eight strided gathers from the interleaved image.
-constexpr int GLW = 64, GLH = 16, GLS = GLW + 4 + 1;
+// Round 5 (was 81 us at 12 MP, 46 % of its LDS cycles in bank conflicts, the image read twice): a thread loads its four
+// pixels ONCE (three 16-B loads), keeps them across the barrier and writes their greens to the LDS tile; only the 2-px halo is
+// gathered separately.  The tile's columns are de-interleaved by 4 (column c at (c >> 2) + (c & 3) * GLQ), so the lanes of
+// a wave -- four pixels apart -- touch consecutive words for every tap; row stride 80 (== 16 mod 32) keeps the two rows of a
+// 32-lane group on disjoint banks.
+constexpr int GLW = 64, GLH = 16;
+constexpr int GLQ = (GLW + 8) / 4;       // 18 words per column class: the tile carries 4 halo columns each side (2 used; keeps groups aligned)
+constexpr int GLS = 80;                  // row stride
+__device__ __forceinline__ int gl_at(int r, int c) { return r * GLS + (c >> 2) + (c & 3) * GLQ; }  // r in [0, 20), c in [0, 72): image (y0 - 2 + r, x0 - 4 + c)
 
 template <int VEC>
 __global__ __launch_bounds__(256) void green_local_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
                                                           uint32_t pattern, float threshold) {
   __shared__ float gt[(GLH + 4) * GLS];
   const int x0 = blockIdx.x * GLW, y0 = blockIdx.y * GLH;
-  for (int i = threadIdx.x; i < (GLW + 4) * (GLH + 4); i += 256) {
-    const int r = i / (GLW + 4), c = i - r * (GLW + 4);
-    const int gx = x0 - 2 + c, gy = y0 - 2 + r;
-    gt[r * GLS + c] = (gx >= 0 && gy >= 0 && gx < width && gy < height) ? in[((size_t)gy * width + gx) * 3 + 1] : 0.0f;
-  }
-  __syncthreads();
-  // VEC == 4: 16 threads x 4 px per row, 16 rows; VEC == 1: 64 threads per row, 4 rows per pass
-  constexpr int TPR = GLW / VEC, RPP = 256 / TPR;
-  const int lx = (threadIdx.x % TPR) * VEC;
-  for (int ly = threadIdx.x / TPR; ly < GLH; ly += RPP) {
+  const int tid = threadIdx.x;
+  auto green_at = [&](int gx, int gy) { return (gx >= 0 && gy >= 0 && gx < width && gy < height) ? in[((size_t)gy * width + gx) * 3 + 1] : 0.0f; };
+  if constexpr (VEC == 4) {
+    // own pixels: 16 threads x 4 px per row, 16 rows
+    const int lx = (tid & 15) * 4, ly = tid >> 4;
     const int x = x0 + lx, y = y0 + ly;
-    if (x >= width || y >= height) continue;
-    const size_t p0 = (size_t)y * width + x;
-    float v[3 * VEC];
-    if constexpr (VEC == 4) rgb4_io<float>::load(in, p0 >> 2, v);
-    else { v[0] = in[p0 * 3]; v[1] = in[p0 * 3 + 1]; v[2] = in[p0 * 3 + 2]; }
+    const bool live = x < width && y < height;  // width % 4 == 0: a group is inside or outside as a whole
+    float v[12];
 #pragma unroll
-    for (int k = 0; k < VEC; k++) {
-      float o = v[3 * k + 1];
-      if (cfa_color(y, x + k, pattern) == 1 && (y & 1)) {
-        const float* g = gt + (ly + 2) * GLS + (lx + k + 2);
+    for (int k = 0; k < 12; k++) v[k] = 0.0f;
+    const size_t p0 = (size_t)y * width + x;
+    if (live) rgb4_io<float>::load(in, p0 >> 2, v);
+    // halo: rows y0 - 2, y0 - 1, y0 + 16, y0 + 17 over columns x0 - 2 .. x0 + 65 (4 x 68), then columns x0 - 2, x0 - 1, x0 + 64,
+    // x0 + 65 of the 16 tile rows (16 x 4): 336 greens
+    float hv[2];
+    int hq[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int i = tid + 256 * u;
+      hq[u] = -1;
+      hv[u] = 0.0f;
+      if (i < 4 * 68) {
+        const int rr = i / 68, c = i - rr * 68, r = rr < 2 ? rr : GLH + rr;  // tile rows 0, 1, 18, 19
+        hq[u] = gl_at(r, c + 2);
+        hv[u] = green_at(x0 - 2 + c, y0 - 2 + r);
+      } else if (i < 4 * 68 + GLH * 4) {
+        const int j = i - 4 * 68, rr = j >> 2, cc = j & 3, c = cc < 2 ? 2 + cc : GLW + 2 + cc;  // tile columns 2, 3, 68, 69
+        hq[u] = gl_at(rr + 2, c);
+        hv[u] = green_at(x0 - 4 + c, y0 + rr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) gt[gl_at(ly + 2, lx + 4 + k)] = v[3 * k + 1];  // (zero outside the image)
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (hq[u] >= 0) gt[hq[u]] = hv[u];
+    __syncthreads();
+    if (!live) return;
+    if (y & 1) {  // wave-uniform per 16-lane row group; G2 sites sit on odd rows only
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float o = v[3 * k + 1];
+        if (cfa_color(y, x + k, pattern) == 1) {
+          // taps of column lx + 4 + k + d: class and word offset are compile-time per (k, d)
+          const int rb = (ly + 2) * GLS + (lx >> 2);
+          auto g = [&](int dy, int dx) { const int kk = 4 + k + dx; return gt[rb + dy * GLS + (kk >> 2) + (kk & 3) * GLQ]; };
+          const float maximum = 1.0f;
+          const float o1_1 = g(-1, -1), o1_2 = g(-1, 1), o1_3 = g(1, -1), o1_4 = g(1, 1);
+          const float o2_1 = g(-2, 0), o2_2 = g(2, 0), o2_3 = g(0, -2), o2_4 = g(0, 2);
+          const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
+          const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
+          if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
+            const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4) + fabsf(o1_2 - o1_4)) / 6.0f;
+            const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4) + fabsf(o2_2 - o2_4)) / 6.0f;
+            if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
+          }
+        }
+        v[3 * k + 1] = o;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[3 * k + 1] = fmaxf(v[3 * k + 1], 0.0f);
+    rgb4_io<float>::store(out, p0 >> 2, v);
+  } else {
+    // unaligned images: the scalar form (green tile gathered, then one pixel per thread)
+    for (int i = tid; i < (GLW + 4) * (GLH + 4); i += 256) {
+      const int r = i / (GLW + 4), c = i - r * (GLW + 4);
+      gt[gl_at(r, c + 2)] = green_at(x0 - 2 + c, y0 - 2 + r);
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    for (int ly = tid >> 6; ly < GLH; ly += 4) {
+      const int x = x0 + lx, y = y0 + ly;
+      if (x >= width || y >= height) continue;
+      const size_t p0 = (size_t)y * width + x;
+      float o = in[p0 * 3 + 1];
+      if (cfa_color(y, x, pattern) == 1 && (y & 1)) {
+        auto g = [&](int dy, int dx) { return gt[gl_at(ly + 2 + dy, lx + 4 + dx)]; };
         const float maximum = 1.0f;
-        const float o1_1 = g[-GLS - 1], o1_2 = g[-GLS + 1], o1_3 = g[GLS - 1], o1_4 = g[GLS + 1];
-        const float o2_1 = g[-2 * GLS], o2_2 = g[2 * GLS], o2_3 = g[-2], o2_4 = g[2];
+        const float o1_1 = g(-1, -1), o1_2 = g(-1, 1), o1_3 = g(1, -1), o1_4 = g(1, 1);
+        const float o2_1 = g(-2, 0), o2_2 = g(2, 0), o2_3 = g(0, -2), o2_4 = g(0, 2);
         const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
         const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
         if ((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f)) {
@@ -232,10 +361,10 @@ __global__ __launch_bounds__(256) void green_local_kernel(const float* __restric
           if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
         }
       }
-      v[3 * k + 1] = fmaxf(o, 0.0f);
+      out[p0 * 3] = in[p0 * 3];
+      out[p0 * 3 + 1] = fmaxf(o, 0.0f);
+      out[p0 * 3 + 2] = in[p0 * 3 + 2];
     }
-    if constexpr (VEC == 4) rgb4_io<float>::store(out, p0 >> 2, v);
-    else { out[p0 * 3] = v[0]; out[p0 * 3 + 1] = v[1]; out[p0 * 3 + 2] = v[2]; }
   }
 }
 
@@ -300,7 +429,7 @@ TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* worksp
     float* dst = dst_of(stage);
     const int n = left < FMAXP ? left : FMAXP;
     TDK_LAUNCH("tdk_postprocess(color_smoothing)", smoothing_fused_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(SNT), 0, s, src, dst, width,
-               height, vec_ok, n);
+               height, (int)(vec_ok && tdk_aligned(src, 16)), (int)(vec_ok && tdk_aligned(dst, 16)), n);
     src = dst;
   }
   if (green_eq_global) {
