@@ -29,6 +29,12 @@ namespace rs {
 // host takes it for every strip launch of such a build
 constexpr int RB = TDK_RS_RB, NT = 512, TWS = 108, HALO = 10;
 constexpr int WG_PER_CU = 2;
+#elif defined(TDK_EXPERIMENTS) && defined(TDK_RS_WG_PER_CU)
+// timing experiment only (wrong results): register budget for TDK_RS_WG_PER_CU workgroups per CU; the launcher is given a smaller
+// LDS allocation through TDK_RCD_LDS_PAD (accesses beyond it are dropped by the hardware)
+constexpr int RB = 8, NT = 512, TWS = 108, HALO = 10;
+constexpr int WG_PER_CU = TDK_RS_WG_PER_CU;
+#define TDK_RS_NO_LDS_ASSERT 1
 #else
 constexpr int RB = 8, NT = 512, TWS = 108, HALO = 10;
 constexpr int WG_PER_CU = 3;
@@ -51,7 +57,9 @@ constexpr int COL_B = PQ_B + (PQ_L + RB) * 64;
 constexpr int LDS_FLOATS = COL_B + (COL_L + RB) * 64 + PAD;
 constexpr int VERDICT_WORDS = 4 * 8;  // [step & 3][wave]
 constexpr size_t LDS_BYTES = (size_t)(LDS_FLOATS + VERDICT_WORDS) * sizeof(float);
+#ifndef TDK_RS_NO_LDS_ASSERT
 static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+#endif
 
 // lags of the steps (rows behind the newest CFA row)
 constexpr int LAG_21 = 1, LAG_11 = 3, LAG_41 = 3, LAG_12 = 4, LAG_42 = 4, LAG_31 = 5, LAG_51 = 7, LAG_52 = 10;

@@ -49,6 +49,7 @@ class ImageProcessor:
         assert storage_dtype in (torch.float32, torch.float16)
         self.storage_dtype = storage_dtype
         self._lum_plane: torch.Tensor | None = None  # lightness plane handed from the denoiser to the bilateral stage
+        self._ab_plane: torch.Tensor | None = None   # ... and the chroma (a, b) plane of the Lab hand-over
         self.metrics: torch.Tensor | None = None  # moving averages, device-resident
         self.bounds: torch.Tensor | None = None
         self.rcd_workspace = _debayer.RCD(device, image_size, bayer_pattern)
@@ -156,15 +157,20 @@ class ImageProcessor:
         if bounds is not None:
             rgb_raw = normalize_image(rgb_raw, bounds)
         s = self.settings
-        lum = None
+        if s.enable_denoise and s.enable_bilateral:
+            # both stages replace the Lab lightness of the same pixel (reference denoise.py:54-58, local_contrast.py:109-114): the
+            # pixel travels between them as lightness + chroma planes and is converted back to RGB once (include/tdk_hip.h, Lab
+            # hand-over; tests/test_gpu_lab_chain.py) instead of as an RGB image through two colour round trips
+            hw = (self.image_size[1], self.image_size[0])
+            if self._lum_plane is None or self._lum_plane.device != rgb_raw.device:
+                self._lum_plane = torch.empty(hw, dtype=torch.float32, device=rgb_raw.device)
+                self._ab_plane = torch.empty((*hw, 2), dtype=torch.float32, device=rgb_raw.device)
+            self.wiener_workspace.process_log_luminance_lab(rgb_raw, s.denoise, luminance_out=self._lum_plane, chroma_out=self._ab_plane)
+            return self.bil_workspace.process_lab(self._lum_plane, self._ab_plane, s.bilateral, out_dtype=rgb_raw.dtype, metrics=metrics)
         if s.enable_denoise:
-            if s.enable_bilateral:
-                if self._lum_plane is None or self._lum_plane.device != rgb_raw.device:
-                    self._lum_plane = torch.empty((self.image_size[1], self.image_size[0]), dtype=torch.float32, device=rgb_raw.device)
-                lum = self._lum_plane
-            rgb_raw = self.wiener_workspace.process_log_luminance(rgb_raw, s.denoise, luminance_out=lum)
+            rgb_raw = self.wiener_workspace.process_log_luminance(rgb_raw, s.denoise)
         if s.enable_bilateral:
-            rgb_raw = self.bil_workspace.process_rgb(rgb_raw, s.bilateral, luminance=lum, metrics=metrics)
+            rgb_raw = self.bil_workspace.process_rgb(rgb_raw, s.bilateral, metrics=metrics)
         elif metrics is not None:
             metrics.add(rgb_raw)
         return rgb_raw
