@@ -109,6 +109,27 @@ def test_batch_on_two_streams_equals_back_to_back(td, dev):
                 assert torch.equal(outs[i], ref[i]), f'frame {i} differs between the {nstreams}-stream and the one-stream run'
     one = FrameStreams(dev, make, streams=1).run(inputs)
     assert all(torch.equal(a, b) for a, b in zip(one, ref))
+    # which RCD strips variant ran: the register-blocked one only when the frames have company (several frames in a batch, or an
+    # earlier batch not yet joined); a lone frame takes the stand-alone kernel, which is the faster one with the GPU to itself
+    from torch_darktable import _native
+
+    runner = FrameStreams(dev, make, streams=3)
+    for batch, want in ((inputs[:3], 'tdk_rcd(concurrent)'), (inputs[:1], 'tdk_rcd')):
+        torch.cuda.synchronize()
+        _native.profile_enable(True)
+        runner.run(batch)
+        torch.cuda.synchronize()
+        names = set(_native.profile_report())
+        _native.profile_enable(False)
+        assert want in names and ({'tdk_rcd', 'tdk_rcd(concurrent)'} - {want}).isdisjoint(names), (len(batch), names)
+    _native.profile_enable(True)
+    runner.issue(inputs[:1])  # not joined ...
+    runner.issue(inputs[1:2])  # ... so this single frame has company
+    torch.cuda.synchronize()
+    names = set(_native.profile_report())
+    _native.profile_enable(False)
+    runner.join()
+    assert {'tdk_rcd', 'tdk_rcd(concurrent)'} <= names, names
 
 
 def test_concurrent_frames_context(td, dev):
