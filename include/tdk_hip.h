@@ -255,9 +255,12 @@ int tdk_bilateral_rgb_lum(const void* rgb_in, const float* lum_in, void* rgb_out
  * one binary16 rounding fewer for float16 images).  Helper: tdk_compute_log_luminance_lab = compute_log_luminance(rgb, eps) +
  * the (a, b) of rgb_to_lab(rgb) in one pass.  workspace of the Wiener call: tdk_wiener_log_luminance_workspace_bytes; of the
  * bilateral call: tdk_bilateral_workspace_bytes (tdk_bilateral_prepare + TDK_BILATERAL_PREPARED as above). */
-int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, int rgb_dtype, tdk_stream_t stream);
+/* bounds (2 device floats or NULL): normalize_image of the reference pipeline (pipeline/util.py:8-10, image_processor.py:257-271),
+ * (x - bounds[0]) / (bounds[1] - bounds[0]), applied to rgb as it is read -- the chain then never stores the normalised image. */
+int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, const float* bounds, int rgb_dtype,
+                                  tdk_stream_t stream);
 int tdk_wiener_log_luminance_lab(const void* rgb_in, void* workspace, int width, int height, int tile_size, int overlap_factor, const float* sigma,
-                                 float eps, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream);
+                                 float eps, const float* bounds, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream);
 int tdk_bilateral_lab(const float* lum_in, const float* ab_in, void* rgb_out, void* workspace, int width, int height, float sigma_s, float sigma_r,
                       float detail, int out_dtype, unsigned flags, tdk_stream_t stream);
 

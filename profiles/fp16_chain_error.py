@@ -22,11 +22,15 @@ out = {}
 for y0, x0 in [(1024, 2048), (2000, 304), (64, 3504)]:
     m, n = 64, 192
     res = {}
-    for storage in ('f16', 'f32'):
-        b = frame.half() if storage == 'f16' else frame
+    for storage in ('f16', 'f32', 'f16 two-stage rgb chain', 'f32 two-stage rgb chain'):
+        b = frame.half() if storage.startswith('f16') else frame
         rgb = td.RCD(dev, (W, H), td.BayerPattern.RGGB).process(b)
-        den = td.Wiener(dev, (W, H)).process_log_luminance(rgb, 0.075)
-        loc = td.Bilateral(dev, (W, H), sigma_s=2.0, sigma_r=0.2).process_rgb(den, 0.4)
+        if 'two-stage' in storage:  # the intermediate RGB image between denoiser and local contrast materialised (bench.py --chain rgb)
+            den = td.Wiener(dev, (W, H)).process_log_luminance(rgb, 0.075)
+            loc = td.Bilateral(dev, (W, H), sigma_s=2.0, sigma_r=0.2).process_rgb(den, 0.4)
+        else:  # the Lab hand-over (what bench.py and the pipeline run)
+            lum, ab = td.Wiener(dev, (W, H)).process_log_luminance_lab(rgb, 0.075)
+            loc = td.Bilateral(dev, (W, H), sigma_s=2.0, sigma_r=0.2).process_lab(lum, ab, 0.4, out_dtype=rgb.dtype)
         bw = b[y0 - m:y0 + n + m, x0 - m:x0 + n + m, 0].float().cpu().numpy()
         r = O.rcd(bw, O.RGGB)
         ll = O.compute_luminance(r, True, 1e-4)

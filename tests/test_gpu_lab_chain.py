@@ -56,7 +56,7 @@ def test_log_luminance_lab_extract(td, oracle, dev, scene):
         x = torch.from_numpy(rgb).to(dev).to(dt)
         ll = torch.empty((h, w), dtype=torch.float32, device=dev)
         ab = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
-        _native.check(_native.lib.tdk_compute_log_luminance_lab(_ptr(x), _ptr(ll), _ptr(ab), h * w, 1e-4, 0 if dt == torch.float32 else 1, _stream()))
+        _native.check(_native.lib.tdk_compute_log_luminance_lab(_ptr(x), _ptr(ll), _ptr(ab), h * w, 1e-4, None, 0 if dt == torch.float32 else 1, _stream()))
         xr = npy(x)
         assert np.abs(npy(ll) - oracle.compute_luminance(xr, True, 1e-4)).max() <= TOL
         lab = oracle.color_op('rgb_to_lab', xr)
@@ -114,6 +114,30 @@ def test_lab_chain_float16_storage(td, dev, size):
     assert rel <= 1.5e-3, rel
     m = acc.finish()
     assert torch.allclose(m, td.compute_image_metrics([out16], stride=8), rtol=2e-5, atol=1e-7)
+
+
+def test_lab_chain_with_the_pipelines_normalisation_folded_in(td, dev):
+    """bounds=: normalize_image(image, bounds) (reference pipeline/util.py:8-10) applied while the first kernel of the chain reads the
+    image.  float32 images: the very bits of normalising first (same IEEE expression); float16 images: the chain skips the binary16
+    rounding of the normalised image, so it agrees with the two-step form within that rounding."""
+    from torch_darktable.pipeline.util import normalize_image
+    from torch_darktable.synthetic import synthetic_rgb
+
+    h, w = 192, 256
+    rgb = synthetic_rgb(h, w, seed=63, device=dev) * 1.7 + 0.05
+    bounds = torch.tensor([0.03, 1.61], device=dev)
+    wiener = td.Wiener(dev, (w, h), overlap_factor=4, tile_size=32)
+    bil = td.Bilateral(dev, (w, h), sigma_s=2.0, sigma_r=0.2)
+    lum1, ab1 = wiener.process_log_luminance_lab(normalize_image(rgb, bounds), 0.075)
+    lum2, ab2 = wiener.process_log_luminance_lab(rgb, 0.075, bounds=bounds)
+    assert torch.equal(lum1, lum2) and torch.equal(ab1, ab2)
+    x16 = rgb.half()
+    out_a = bil.process_lab(*wiener.process_log_luminance_lab(normalize_image(x16, bounds), 0.075), 0.4, out_dtype=torch.float16)
+    out_b = bil.process_lab(*wiener.process_log_luminance_lab(x16, 0.075, bounds=bounds), 0.4, out_dtype=torch.float16)
+    rel = ((out_a.float() - out_b.float()).abs() / out_a.float().amax(-1, keepdim=True).clamp_min(0.05)).max().item()
+    assert rel <= 1.5e-3, rel
+    with pytest.raises(RuntimeError):
+        wiener.process_log_luminance_lab(rgb, 0.075, bounds=torch.tensor([0.0, 1.0]))  # bounds on the host
 
 
 def test_lab_chain_argument_checks(td, dev):

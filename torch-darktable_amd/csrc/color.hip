@@ -110,14 +110,22 @@ __global__ __launch_bounds__(256) void lum_extract_tail(const TR* __restrict__ r
 // for the pixels the reference's clip to [0, 1] changes), and the bilateral epilogue converts (L'', a, b) to RGB once.
 // Per pixel 13 + 1 + 6 transcendentals instead of 9 + 27 + 18.  Same values as the two-stage chain up to the rounding of the
 // skipped sRGB encode -> (store) -> decode round trip: parity by the colour operators' tolerance (2e-5), not bit for bit.
+// bounds (nullable): the pipeline's normalize_image, (x - bounds[0]) / (bounds[1] - bounds[0]) (reference pipeline/util.py:8-10), applied
+// to the samples as they are loaded -- the same IEEE expression as normalize_kernel below, so for float32 images the result is
+// that of normalize_image followed by this kernel, without the normalised image ever being stored
 template <typename TR, int VEC>
 __global__ __launch_bounds__(256) void lum_lab_extract(const TR* __restrict__ rgb, float* __restrict__ loglum, float* __restrict__ ab, int64_t first,
-                                                       int64_t ngroups, float eps) {
+                                                       int64_t ngroups, float eps, const float* __restrict__ bounds) {
   TDK_STREAMING_KERNEL_PROLOGUE();
+  const float b0 = bounds ? bounds[0] : 0.0f, range = bounds ? bounds[1] - bounds[0] : 1.0f;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
     float v[3 * VEC], l[VEC], c2[2 * VEC];
     if constexpr (VEC == 4) rgb4_io<TR>::load(rgb, g, v);
     else { v[0] = ld(rgb, 3 * (first + g)); v[1] = ld(rgb, 3 * (first + g) + 1); v[2] = ld(rgb, 3 * (first + g) + 2); }
+    if (bounds) {  // kernel argument: uniform
+#pragma unroll
+      for (int k = 0; k < 3 * VEC; k++) v[k] = (v[k] - b0) / range;
+    }
     bool outside = false;
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
@@ -264,7 +272,8 @@ TDK_EXPORT int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, i
   TDK_LUM_DISPATCH(run_extract, rgb, lum, npix, eps, tdk_stream(stream));
 }
 
-TDK_EXPORT int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, int rgb_dtype, tdk_stream_t stream) {
+TDK_EXPORT int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, float* ab, int64_t npix, float eps, const float* bounds, int rgb_dtype,
+                                             tdk_stream_t stream) {
   TDK_REQUIRE(npix >= 0, "tdk_compute_log_luminance_lab: negative pixel count");
   if (npix == 0) return TDK_OK;
   TDK_REQUIRE(rgb && loglum && ab, "tdk_compute_log_luminance_lab: null pointer");
@@ -275,10 +284,10 @@ TDK_EXPORT int tdk_compute_log_luminance_lab(const void* rgb, float* loglum, flo
     int64_t done = 0;
     if (tdk_aligned(rgb, 16) && tdk_aligned(loglum, 16) && tdk_aligned(ab, 16) && npix >= 4) {
       const int64_t ng = npix / 4;
-      TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 4>), dim3(stream_grid(ng)), dim3(256), 0, s, in, loglum, ab, (int64_t)0, ng, eps);
+      TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 4>), dim3(stream_grid(ng)), dim3(256), 0, s, in, loglum, ab, (int64_t)0, ng, eps, bounds);
       done = ng * 4;
     }
-    if (done < npix) TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 1>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, loglum, ab, done, npix - done, eps);
+    if (done < npix) TDK_LAUNCH("tdk_compute_luminance(lab)", (lum_lab_extract<T, 1>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, loglum, ab, done, npix - done, eps, bounds);
   });
   return TDK_OK;
 }

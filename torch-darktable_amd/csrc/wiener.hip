@@ -933,14 +933,14 @@ int launch_log_luminance(const void* rgb_in, void* rgb_out, void* workspace, int
 // The Lab hand-over form of Wiener.process_log_luminance: extract log-L + (a, b) -> tiles -> wiener_finish_lab.
 template <int K>
 int launch_log_luminance_lab(const void* rgb_in, void* workspace, int W, int H, int ov, const float* sigma, float eps, int dtype, hipStream_t st_, float* lum_out,
-                             float* ab_out) {
+                             float* ab_out, const float* bounds) {
   TDK_REQUIRE(window_table_ok<K>(), "tdk_wiener: the compiled-in window table does not match make_window()");
   const bool ysk = use_ystream(K, ov);
   const Geom g = ysk ? geometry_ys(W, H, pick_segment_rows(W, H, 1)) : geometry(W, H, K, ov, pick_group_width(W, H, K, ov, 1, tiles_per_cu(K, ov)));
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
-  int rc = tdk_compute_log_luminance_lab(rgb_in, plane, ab_out, (int64_t)W * H, eps, dtype, reinterpret_cast<tdk_stream_t>(st_));
+  int rc = tdk_compute_log_luminance_lab(rgb_in, plane, ab_out, (int64_t)W * H, eps, bounds, dtype, reinterpret_cast<tdk_stream_t>(st_));
   if (rc != TDK_OK) return rc;
   rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
@@ -1019,7 +1019,7 @@ TDK_EXPORT int tdk_wiener_log_luminance_lum(const void* rgb_in, void* rgb_out, v
 }
 
 TDK_EXPORT int tdk_wiener_log_luminance_lab(const void* rgb_in, void* workspace, int width, int height, int tile_size, int overlap_factor, const float* sigma,
-                                            float eps, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream) {
+                                            float eps, const float* bounds, int dtype, float* lum_out, float* ab_out, tdk_stream_t stream) {
   TDK_REQUIRE(rgb_in && workspace && sigma && lum_out && ab_out, "tdk_wiener_log_luminance_lab: null pointer");
   TDK_REQUIRE(tile_size == 16 || tile_size == 32, "tile_size must be 16 or 32, got %d", tile_size);
   TDK_REQUIRE(overlap_factor == 2 || overlap_factor == 4 || overlap_factor == 8, "overlap_factor must be 2, 4, or 8");
@@ -1027,6 +1027,6 @@ TDK_EXPORT int tdk_wiener_log_luminance_lab(const void* rgb_in, void* workspace,
   TDK_REQUIRE(eps > 0.0f, "Epsilon must be positive");
   TDK_REQUIRE(dtype == TDK_F32 || dtype == TDK_F16, "unsupported dtype tag %d", dtype);
   hipStream_t s = tdk_stream(stream);
-  if (tile_size == 16) return launch_log_luminance_lab<16>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out);
-  return launch_log_luminance_lab<32>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out);
+  if (tile_size == 16) return launch_log_luminance_lab<16>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out, bounds);
+  return launch_log_luminance_lab<32>(rgb_in, workspace, width, height, overlap_factor, sigma, eps, dtype, s, lum_out, ab_out, bounds);
 }

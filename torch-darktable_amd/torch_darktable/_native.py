@@ -67,8 +67,8 @@ SIGNATURES = {
   'tdk_wiener_log_luminance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p]),
   'tdk_wiener_log_luminance_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_int, c_float, c_void_p]),
   'tdk_bilateral_rgb_lum': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
-  'tdk_compute_log_luminance_lab': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
-  'tdk_wiener_log_luminance_lab': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+  'tdk_compute_log_luminance_lab': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int, c_void_p]),
+  'tdk_wiener_log_luminance_lab': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
   'tdk_bilateral_lab': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, C.c_uint, c_void_p]),
   'tdk_bilateral_grid_size': (c_int, [c_int, c_int, c_float, c_float, C.POINTER(c_int)]),
   'tdk_bilateral_workspace_bytes': (c_size_t, [c_int, c_int, c_float, c_float]),

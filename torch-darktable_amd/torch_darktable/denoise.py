@@ -82,15 +82,16 @@ class Wiener:
         return self._wiener.process_log_luminance(image, self._sigmas(noise, 1), eps, luminance_out)
 
     def process_log_luminance_lab(self, image: torch.Tensor, noise, eps: float = 1e-4, *, luminance_out: torch.Tensor | None = None,
-                                  chroma_out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+                                  chroma_out: torch.Tensor | None = None, bounds: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
         """process_log_luminance for a consumer that takes the pixel as Lab (local_contrast.Bilateral.process_lab): returns
         (luminance, chroma) = the float32 (H, W) lightness plane of the denoised image and the float32 (H, W, 2) plane of its
         Lab (a, b), without forming the denoised RGB image.  The two stages then share ONE colour round trip; results agree
-        with process_log_luminance -> process_rgb within the colour operators' tolerance."""
+        with process_log_luminance -> process_rgb within the colour operators' tolerance.  `bounds`: normalise the image as
+        pipeline.util.normalize_image(image, bounds) would, while it is read (the pipeline's step before the denoiser)."""
         expected = (self._wiener.height, self._wiener.width, 3)
         if tuple(image.shape) != expected:
             raise RuntimeError(f'Wiener input shape {tuple(image.shape)} != expected {expected}')
-        return self._wiener.process_log_luminance_lab(image, self._sigmas(noise, 1), eps, luminance_out, chroma_out)
+        return self._wiener.process_log_luminance_lab(image, self._sigmas(noise, 1), eps, luminance_out, chroma_out, bounds)
 
     def process_log(self, image: torch.Tensor, noise, eps: float = 1e-4) -> torch.Tensor:
         return self.process((image + eps).log(), noise).exp()

@@ -154,10 +154,11 @@ class ImageProcessor:
         """normalise -> [denoise] -> [local contrast].  When both stages run, the denoiser hands the lightness plane of
         its result to the bilateral (which would extract it first); with `metrics` the result is also added to that
         accumulator -- same results as the separate calls."""
-        if bounds is not None:
-            rgb_raw = normalize_image(rgb_raw, bounds)
         s = self.settings
-        if s.enable_denoise and s.enable_bilateral:
+        both = s.enable_denoise and s.enable_bilateral
+        if bounds is not None and not both:
+            rgb_raw = normalize_image(rgb_raw, bounds)
+        if both:
             # both stages replace the Lab lightness of the same pixel (reference denoise.py:54-58, local_contrast.py:109-114): the
             # pixel travels between them as lightness + chroma planes and is converted back to RGB once (include/tdk_hip.h, Lab
             # hand-over; tests/test_gpu_lab_chain.py) instead of as an RGB image through two colour round trips
@@ -165,7 +166,8 @@ class ImageProcessor:
             if self._lum_plane is None or self._lum_plane.device != rgb_raw.device:
                 self._lum_plane = torch.empty(hw, dtype=torch.float32, device=rgb_raw.device)
                 self._ab_plane = torch.empty((*hw, 2), dtype=torch.float32, device=rgb_raw.device)
-            self.wiener_workspace.process_log_luminance_lab(rgb_raw, s.denoise, luminance_out=self._lum_plane, chroma_out=self._ab_plane)
+            # (normalize_image rides in the first kernel of the chain: the normalised image is never stored)
+            self.wiener_workspace.process_log_luminance_lab(rgb_raw, s.denoise, luminance_out=self._lum_plane, chroma_out=self._ab_plane, bounds=bounds)
             return self.bil_workspace.process_lab(self._lum_plane, self._ab_plane, s.bilateral, out_dtype=rgb_raw.dtype, metrics=metrics)
         if s.enable_denoise:
             rgb_raw = self.wiener_workspace.process_log_luminance(rgb_raw, s.denoise)

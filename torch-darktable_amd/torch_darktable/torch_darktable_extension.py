@@ -704,11 +704,12 @@ class Wiener(_Workspace):
 
 
   def process_log_luminance_lab(self, image: torch.Tensor, noise_sigmas: torch.Tensor, eps: float = 1e-4, luminance_out: torch.Tensor | None = None,
-                                chroma_out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+                                chroma_out: torch.Tensor | None = None, bounds: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
     """Lab hand-over form of process_log_luminance (include/tdk_hip.h: tdk_wiener_log_luminance_lab): instead of the denoised RGB
     image it returns (luminance, chroma) = the float32 (H, W) plane compute_luminance(denoised) and the float32 (H, W, 2) plane
     of the denoised pixels' Lab (a, b) -- what Bilateral.process_lab takes.  The RGB image between the two stages is never
-    formed: one colour round trip for the two stages instead of two (tolerance of the colour operators, not bit for bit)."""
+    formed: one colour round trip for the two stages instead of two (tolerance of the colour operators, not bit for bit).
+    bounds: optional 2 device floats; the image is normalised as pipeline.util.normalize_image(image, bounds) would while it is read."""
     _check_rgb(image, 'image', allow_half=True)
     _require(image.device == self._device, 'input device mismatch')
     _require(image.size(0) == self._height and image.size(1) == self._width, 'Input dimensions must match workspace size')
@@ -724,8 +725,10 @@ class Wiener(_Workspace):
     with torch.cuda.device(x.device):
       nbytes = lib.tdk_wiener_log_luminance_workspace_bytes(self._width, self._height, self._tile_size, self._overlap_factor)
       ws = self._workspace(nbytes, x.device)
+      if bounds is not None:
+        _require(bounds.dtype == torch.float32 and bounds.numel() == 2 and bounds.device == x.device and bounds.is_contiguous(), 'bounds must be 2 float32 values on the image device')
       check(lib.tdk_wiener_log_luminance_lab(_ptr(x), _ptr(ws), self._width, self._height, self._tile_size, self._overlap_factor, _ptr(sig), float(eps),
-                                             _dtype_tag(x), _ptr(lum), _ptr(ab), _stream()))
+                                             _ptr(bounds), _dtype_tag(x), _ptr(lum), _ptr(ab), _stream()))
     return lum, ab
 
 
