@@ -28,6 +28,9 @@
 // the oracle, no FMA contraction, IEEE divides -> bit-exact.
 #include "tdk_fastdiv.h"
 #include "tdk_stencils.h"
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RQ_FAKE_LAB)
+#include "tdk_color.h"
+#endif
 
 #ifdef TDK_RCD_TIMING
 // experiments: per-phase clock64() deltas of one workgroup, summed over its tiles (profiles/rcd_phase_exp.py)

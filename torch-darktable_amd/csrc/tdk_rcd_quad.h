@@ -419,6 +419,16 @@ __device__ __forceinline__ void q_step_5_2_out(const Lane& t, bool red_row, T* _
       const float f0 = p == 0 ? rr_ : gr_, f1 = p == 0 ? green : gg, f2 = p == 0 ? rb_ : gb_;
       const float s0 = p == 0 ? gr_ : rr_, s1 = p == 0 ? gg : green, s2 = p == 0 ? gb_ : rb_;
       if (st0 && st1) {
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RQ_FAKE_LAB)
+        // timing experiment only (profiles/rcd_lab_fusion_exp.py; the caller's buffer holds 12 bytes per pixel): what it would cost this
+        // kernel to emit log-lightness + Lab chroma instead of RGB, i.e. to absorb lum_lab_extract
+        if constexpr (sizeof(T) == 2) {
+          const f3 l0 = cA::rgb_to_lab(mk3(f0, f1, f2)), l1 = cA::rgb_to_lab(mk3(s0, s1, s2));
+          struct alignas(8) px6 { float a, b, c, d, e, f; };
+          *reinterpret_cast<px6*>(reinterpret_cast<float*>(dst) + 6 * k) =
+              px6{tdk_log(fmaxf(1e-4f, fmaxf(l0.x, 0.0f))), l0.y, l0.z, tdk_log(fmaxf(1e-4f, fmaxf(l1.x, 0.0f))), l1.y, l1.z};
+        } else
+#endif
         if constexpr (sizeof(T) == 4) {
           struct alignas(8) px6 { float a, b, c, d, e, f; };
           *reinterpret_cast<px6*>(d) = px6{f0, f1, f2, s0, s1, s2};
@@ -574,7 +584,11 @@ __global__ __launch_bounds__(Geo<CPL>::NT) __attribute__((amdgpu_waves_per_eu(Ge
 #pragma unroll
     for (int ci = 0; ci < CPL; ci++) st[ci] = rout && ((own7 >> ci) & 1) != 0;
     const lmask stm = __builtin_amdgcn_ballot_w64(rout) & own_lanes;
+#if defined(TDK_EXPERIMENTS) && defined(TDK_RQ_FAKE_LAB)
+    T* dst = sizeof(T) == 2 ? reinterpret_cast<T*>(reinterpret_cast<float*>(out) + ((size_t)gyo * w + t.gxq) * 3) : out + ((size_t)gyo * w + t.gxq) * 3;
+#else
     T* dst = out + ((size_t)gyo * w + t.gxq) * 3;
+#endif
 
 #define RQ_STEP(MODEV, PEV)                                              \
   do {                                                                   \

@@ -940,7 +940,11 @@ int launch_log_luminance_lab(const void* rgb_in, void* workspace, int W, int H, 
   const WParams prm = make_params<K>(g, ov);
   float* slabs = reinterpret_cast<float*>(workspace);
   float* plane = slabs + tdk_align_up(slab_cap_floats(W, H, K, ov), 64);
-  int rc = tdk_compute_log_luminance_lab(rgb_in, plane, ab_out, (int64_t)W * H, eps, bounds, dtype, reinterpret_cast<tdk_stream_t>(st_));
+  int rc = TDK_OK;
+#ifdef TDK_EXPERIMENTS
+  if (!getenv("TDK_FAKE_SKIP_EXTRACT"))  // timing experiment (profiles/rcd_lab_fusion_exp.py): the producer is assumed to have filled the planes
+#endif
+  rc = tdk_compute_log_luminance_lab(rgb_in, plane, ab_out, (int64_t)W * H, eps, bounds, dtype, reinterpret_cast<tdk_stream_t>(st_));
   if (rc != TDK_OK) return rc;
   rc = ysk ? launch_tiles_ys<float>(plane, slabs, W, H, 1, 0, sigma, g, st_, 1) : launch_tiles<float, K>(plane, slabs, W, H, 1, 0, ov, sigma, g, prm, st_);
   if (rc != TDK_OK) return rc;
