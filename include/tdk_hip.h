@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TDK_ABI_VERSION 3
+#define TDK_ABI_VERSION 4
 
 typedef void* tdk_stream_t; /* hipStream_t */
 
@@ -269,6 +269,22 @@ int tdk_bilateral_lab(const float* lum_in, const float* ab_in, void* rgb_out, vo
 size_t tdk_laplacian_workspace_bytes(int width, int height, int num_gamma);
 int tdk_laplacian(const float* lum_in, float* lum_out, void* workspace, int width, int height, int num_gamma, float sigma,
                   float shadows, float highlights, float clarity, tdk_stream_t stream);
+
+/* ---- Jpeg.encode: reference csrc/jpeg_encoder.cu:104-180 (extension.cpp:226-246), an nvjpeg wrapper: nvjpegEncodeImage with
+ * quality, optimised Huffman tables, sampling factors 444 / 422 / GRAY, baseline or progressive, then
+ * nvjpegEncodeRetrieveBitstream (length query, then the bytes).  Here a device encoder (csrc/jpeg.hip) in the same two steps:
+ * tdk_jpeg_encode runs colour conversion, FDCT, quantisation, Huffman coding and byte stuffing on the GPU, leaves the JFIF stream
+ * in `workspace` (tdk_jpeg_workspace_bytes, 256-byte aligned) and returns its length; tdk_jpeg_retrieve copies it to host memory.
+ * image: uint8 on the device, contiguous; input_format 0 = BGR and 1 = RGB planar (3, H, W), 2 = BGRI and 3 = RGBI interleaved
+ * (H, W, 3) (JpegInputFormat, csrc/jpeg_encoder.h); subsampling 0 = 4:4:4, 1 = 4:2:2, 2 = gray (JpegSubsampling).
+ * tdk_jpeg_encode synchronises `stream` (once per scan for the Huffman statistics, once at the end), like the reference's call.
+ * tdk_jpeg_coefficients (tests): the quantised coefficients of the last encode, 64 zig-zag int16 per block, component planes
+ * (padded to whole MCUs) back to back. */
+size_t tdk_jpeg_workspace_bytes(int width, int height, int subsampling);
+int tdk_jpeg_encode(const void* image, int width, int height, int input_format, int quality, int subsampling, int progressive,
+                    void* workspace, size_t* length, tdk_stream_t stream);
+int tdk_jpeg_retrieve(const void* workspace, int width, int height, int subsampling, uint8_t* out_host, size_t length, tdk_stream_t stream);
+int tdk_jpeg_coefficients(const void* workspace, int width, int height, int subsampling, int16_t* out_host, tdk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -339,3 +339,24 @@ def rgb_to_bayer(rgb: np.ndarray, pattern: int = RGGB) -> np.ndarray:
   out[1::2, 0::2] = rgb[1:h // 2 * 2:2, 0:w // 2 * 2:2, ch[2]]
   out[1::2, 1::2] = rgb[1:h // 2 * 2:2, 1:w // 2 * 2:2, ch[3]]
   return out[:, :, None]
+
+
+# ------------------------------------------------------------------ JPEG (the format after the path; oracle/src/jpeg.c)
+def jpeg_encode(img: np.ndarray, quality: int = 94, input_format: int = 3, subsampling: int = 1, progressive: bool = False,
+                return_coefs: bool = False):
+  """uint8 image, (H, W, 3) for the interleaved formats (2 = BGRI, 3 = RGBI) or (3, H, W) for the planar ones (0 = BGR,
+  1 = RGB) -> the JPEG byte stream as a uint8 array (and the quantised zig-zag coefficients, component planes back to back)."""
+  img = np.ascontiguousarray(img, dtype=np.uint8)
+  h, w = (img.shape[1], img.shape[2]) if input_format < 2 else (img.shape[0], img.shape[1])
+  hs = 2 if subsampling == 1 else 1
+  nmx, nmy = -(-w // (8 * hs)), -(-h // 8)
+  nblocks = nmx * nmy * (1 if subsampling == 2 else hs + 2)
+  cap = 1024 + nblocks * 420
+  out = np.empty(cap, np.uint8)
+  coefs = np.empty(nblocks * 64, np.int16) if return_coefs else None
+  f = lib().oracle_jpeg_encode
+  f.restype = C.c_int64
+  n = f(_p(img), C.c_int(w), C.c_int(h), C.c_int(input_format), C.c_int(quality), C.c_int(subsampling), C.c_int(bool(progressive)),
+        _p(out), C.c_int64(cap), _p(coefs) if return_coefs else None)
+  assert 0 < n <= cap
+  return (out[:n].copy(), coefs) if return_coefs else out[:n].copy()

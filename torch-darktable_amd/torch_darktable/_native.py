@@ -80,6 +80,10 @@ SIGNATURES = {
   'tdk_bilateral_rgb': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
   'tdk_laplacian_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
   'tdk_laplacian': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+  'tdk_jpeg_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+  'tdk_jpeg_encode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(c_size_t), c_void_p]),
+  'tdk_jpeg_retrieve': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+  'tdk_jpeg_coefficients': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 TDK_F32, TDK_F16 = 0, 1
@@ -96,8 +100,8 @@ def load() -> C.CDLL:
     fn = getattr(lib, name)  # AttributeError here == ABI mismatch between header and library
     fn.restype = restype
     fn.argtypes = argtypes
-  if lib.tdk_abi_version() != 3:
-    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 3')
+  if lib.tdk_abi_version() != 4:
+    raise ImportError(f'libtdk_hip.so ABI version {lib.tdk_abi_version()} != 4')
   return lib
 
 

@@ -1,5 +1,5 @@
 """JPEG front-end (reference torch_darktable/jpeg.py).  The reference wraps nvjpeg; here the encoder
-is a host (Pillow / libjpeg-turbo) backend behind the same API -- see extension.Jpeg."""
+is the device encoder of csrc/jpeg.hip behind the same API -- see extension.Jpeg."""
 
 from enum import IntEnum
 

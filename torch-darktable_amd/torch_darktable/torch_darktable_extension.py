@@ -906,43 +906,47 @@ globals().update(JpegSubsampling.__members__)
 
 
 class Jpeg:
-  """Same call signature and result type (CPU uint8 tensor holding the JPEG bitstream) as the
-  reference's nvjpeg wrapper (csrc/jpeg_encoder.cu:104-180).  There is no ROCm counterpart of
-  nvjpeg in this environment and no HIP kernel to write, so this is a HOST encoder (Pillow /
-  libjpeg-turbo, optimised Huffman tables like the reference): it copies the uint8 image to the
-  host first.  It is not part of the measured kernel hot path; bit-identity with nvjpeg output is
-  neither expected nor testable here (parity unpinned)."""
+  """Jpeg.encode of the reference (csrc/jpeg_encoder.cu:104-180, an nvjpeg wrapper): uint8 image on the device in, the JPEG byte
+  stream as a CPU uint8 tensor out; optimised Huffman tables, 4:4:4 / 4:2:2 / gray, baseline or progressive.  The encoder is
+  the device encoder of csrc/jpeg.hip (colour conversion, FDCT, quantisation, Huffman coding and byte stuffing on the GPU; only the
+  finished stream crosses PCIe).  nvjpeg's exact bytes are not reproducible (closed library, nothing pinned in the reference):
+  the stream is checked against the CPU restatement of T.81 in oracle/ byte for byte and against libjpeg's decode.
+  Checks and messages as in the reference (createImage, interleavedImage / planarImage)."""
+
+  def __init__(self):
+    self._workspace = None  # (key, tensor): the coder's scratch is kept between calls like nvjpeg's encoder state
 
   def encode(self, image: torch.Tensor, quality: int, input_format: int, subsampling: int, progressive: bool) -> torch.Tensor:
-    import io
-
-    from PIL import Image
-
-    if image.dtype != torch.uint8:
-      raise RuntimeError('Input image should be uint8')
-    if not image.is_contiguous():
-      raise RuntimeError('Input data should be contiguous')
-    fmt, sub = JpegInputFormat(int(input_format)), JpegSubsampling(int(subsampling))
     try:
-      arr = image.detach().cpu()
-      if fmt in (JpegInputFormat.BGR, JpegInputFormat.RGB):  # planar (3, H, W)
-        arr = arr.permute(1, 2, 0)
-      if arr.dim() != 3 or arr.size(2) != 3:
-        raise JpegException(f'expected a 3-channel image, got shape {tuple(image.shape)}')
-      if fmt in (JpegInputFormat.BGR, JpegInputFormat.BGRI):
-        arr = arr.flip(2)
-      pil = Image.fromarray(arr.contiguous().numpy(), 'RGB')
-      buf = io.BytesIO()
-      if sub == JpegSubsampling.CSS_GRAY:
-        pil.convert('L').save(buf, 'JPEG', quality=int(quality), optimize=True, progressive=bool(progressive))
-      else:
-        pil.save(buf, 'JPEG', quality=int(quality), optimize=True, progressive=bool(progressive),
-                 subsampling='4:4:4' if sub == JpegSubsampling.CSS_444 else '4:2:2')
-    except JpegException:
-      raise
-    except Exception as e:  # noqa: BLE001
-      raise JpegException(f'JPEG encode failed: {e}') from e
-    return torch.frombuffer(bytearray(buf.getvalue()), dtype=torch.uint8)
+      fmt, sub = JpegInputFormat(int(input_format)), JpegSubsampling(int(subsampling))
+    except ValueError as e:
+      raise RuntimeError(f'Invalid input format or subsampling: {e}') from e
+    _require(image.is_cuda, 'Input image should be on CUDA device')
+    _require(image.dtype == torch.uint8, 'Input image should be uint8')
+    _require(image.is_contiguous(), 'Input data should be contiguous')
+    if fmt in (JpegInputFormat.BGRI, JpegInputFormat.RGBI):
+      _require(image.dim() == 3 and image.size(2) == 3, 'for interleaved (BGRI, RGBI) expected 3D tensor (H, W, C)')
+      h, w = int(image.size(0)), int(image.size(1))
+    else:
+      _require(image.dim() == 3 and image.size(0) == 3, 'for planar (BGR, RGB) expected 3D tensor (C, H, W)')
+      h, w = int(image.size(1)), int(image.size(2))
+    with torch.cuda.device(image.device):
+      nbytes = lib.tdk_jpeg_workspace_bytes(w, h, int(sub))
+      if nbytes == 0:
+        raise JpegException(f'nvjpegEncodeImage, image {w}x{h} not supported')
+      key = (w, h, int(sub), image.device)
+      if self._workspace is None or self._workspace[0] != key:
+        self._workspace = (key, torch.empty(nbytes, dtype=torch.uint8, device=image.device))
+      ws = self._workspace[1]
+      length = C.c_size_t(0)
+      rc = lib.tdk_jpeg_encode(_ptr(image), w, h, int(fmt), int(quality), int(sub), int(bool(progressive)), _ptr(ws), C.byref(length), _stream())
+      if rc != 0:
+        raise JpegException(f'nvjpegEncodeImage, {lib.tdk_last_error().decode()}')
+      buffer = torch.empty(int(length.value), dtype=torch.uint8)
+      rc = lib.tdk_jpeg_retrieve(_ptr(ws), w, h, int(sub), C.c_void_p(buffer.data_ptr()), length, _stream())
+      if rc != 0:
+        raise JpegException(f'nvjpegEncodeRetrieveBitstream, {lib.tdk_last_error().decode()}')
+    return buffer
 
   def __repr__(self) -> str:
     return 'Jpeg'
