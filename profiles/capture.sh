@@ -17,11 +17,11 @@ python3 bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > $OUT/benc
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_isp_under_rocprof.json 2> $OUT/rocprof_stats.err || exit 1
 # the same command with the frames back to back on one stream: per-kernel durations with the GPU to themselves
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench -- python3 bench.py --steps 5 --warmup 2 --streams 1 --no-cpu-baseline > $OUT/bench_isp_streams1_under_rocprof.json 2> $OUT/rocprof_stats1.err || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_write.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/valu -o v -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_valu.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -o s -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq2.log 2>&1 || echo "sq2 pass failed (optional)"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/sq3 -o t -- python3 profiles/run_op.py isp --iters 3 > $OUT/pmc_sq3.log 2>&1 || echo "sq3 pass failed (optional)"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 profiles/run_op.py isp_jpeg --iters 3 > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 profiles/run_op.py isp_jpeg --iters 3 > $OUT/pmc_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/valu -o v -- python3 profiles/run_op.py isp_jpeg --iters 3 > $OUT/pmc_valu.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -o s -- python3 profiles/run_op.py isp_jpeg --iters 3 > $OUT/pmc_sq2.log 2>&1 || echo "sq2 pass failed (optional)"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/sq3 -o t -- python3 profiles/run_op.py isp_jpeg --iters 3 > $OUT/pmc_sq3.log 2>&1 || echo "sq3 pass failed (optional)"
 python3 profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json $OUT/valu $GIT $OUT/sq2 $OUT/sq3 > $OUT/traffic.log 2>&1 || exit 1
 # the bench line again, now that the counters of these sources exist (roofline.valu / roofline.composite need them)
 cp $OUT/traffic.json profiles/traffic.json
@@ -30,5 +30,6 @@ python3 bench.py --steps 10 --warmup 3 --streams 2 --no-cpu-baseline > $OUT/benc
 python3 profiles/op_bench.py --storage f16 > $OUT/op_bench_f16.json 2> $OUT/op_bench_f16.err || echo "op bench f16 failed"
 python3 profiles/op_bench.py --storage f32 > $OUT/op_bench_f32.json 2> $OUT/op_bench_f32.err || echo "op bench f32 failed"
 python3 profiles/op_bench.py --storage f16 --width 8192 --height 6144 --only "PPG|Wiener.process C=3" > $OUT/op_bench_50mp_f16.json 2> $OUT/op_bench_50mp_f16.err || echo "op bench 50 MP failed"
+python3 profiles/jpeg_bench.py --pillow > $OUT/jpeg_bench.txt 2>&1 || echo "jpeg bench failed"
 python3 profiles/laplacian_kernels.py > $OUT/laplacian_kernels.txt 2>&1 || echo "laplacian kernels failed"
 echo capture done

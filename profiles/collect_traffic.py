@@ -56,6 +56,13 @@ KERNELS = {
     # 8-B / 16-B per-lane streaming loads: calibrated on these kernels' known byte counts (12 MP fp16:
     # tonemap reads 75.5 MB, FETCH_SIZE reported 37.8 MB) -> the factor 2 applies to them as well
     'tonemap_vec4': ('tdk_tonemap', True),
+    # JPEG (run_op.py isp_jpeg): dword / byte image reads and one 128-byte coefficient line per lane -- no wide streams
+    'jpeg_fdct_kernel': ('tdk_jpeg(fdct)', False),
+    'jpeg_code_kernel<0>': ('tdk_jpeg(histogram)', False),
+    'jpeg_code_kernel<1>': ('tdk_jpeg(lengths)', False),
+    'jpeg_code_kernel<2>': ('tdk_jpeg(write)', False),
+    'jpeg_stuff_kernel<false>': ('tdk_jpeg(count ff)', True),
+    'jpeg_stuff_kernel<true>': ('tdk_jpeg(stuff)', True),
     'lum_modify_vec4': ('tdk_modify_luminance', True),
     'lum_extract_vec4': ('tdk_compute_luminance', True),
 }

@@ -1,7 +1,7 @@
 """Run one op of the hot path a few times on synthetic 12 MP data -- the target of the
 rocprofv3 passes whose summaries are committed in this directory.
 
-  python profiles/run_op.py {rcd,ppg,postprocess,wiener,bilateral,laplacian,tonemap,luminance,isp} [--iters N] [--storage f16|f32]
+  python profiles/run_op.py {rcd,ppg,postprocess,wiener,bilateral,laplacian,tonemap,luminance,jpeg,isp,isp_jpeg} [--iters N] [--storage f16|f32]
 """
 import argparse
 import sys
@@ -45,6 +45,8 @@ def main():
     lum_plane = torch.empty((h, w), dtype=torch.float32, device=dev)
     ab_plane = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
     acc = td.tonemap.MetricsAccumulator(dev, stride=8)
+    jpeg = td.Jpeg()
+    u8 = td.reinhard_tonemap(rgb, metrics, params)
     torch.cuda.synchronize()
     for _ in range(a.iters):
         if a.op == 'rcd':
@@ -69,6 +71,14 @@ def main():
             wiener.process_log_luminance_lab(x, 0.075, luminance_out=lum_plane, chroma_out=ab_plane)
             x = bil.process_lab(lum_plane, ab_plane, 0.4, out_dtype=x.dtype, metrics=acc)
             td.reinhard_tonemap(x, acc.finish(), params)
+        elif a.op == 'isp_jpeg':  # the chain + the format after it: Jpeg.encode of the tone-mapped frame (4:2:2, quality 94, baseline)
+            with td.torch_darktable_extension.concurrent_frames():
+                x = rcd.process(bayer)
+            wiener.process_log_luminance_lab(x, 0.075, luminance_out=lum_plane, chroma_out=ab_plane)
+            x = bil.process_lab(lum_plane, ab_plane, 0.4, out_dtype=x.dtype, metrics=acc)
+            jpeg.encode(td.reinhard_tonemap(x, acc.finish(), params))
+        elif a.op == 'jpeg':
+            jpeg.encode(u8)
         elif a.op == 'isp_rgb':  # the same chain with the intermediate RGB image materialised (bench.py --chain rgb)
             with td.torch_darktable_extension.concurrent_frames():
                 x = rcd.process(bayer)

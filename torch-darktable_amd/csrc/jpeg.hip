@@ -62,6 +62,11 @@ struct ScanDesc {
   long long nscan;             // blocks the scan codes
 };
 
+// Coefficient store: block idx keeps its 64 zig-zag int16 as 32 dwords, dword j of block idx at ((idx / 64) * 32 + j) * 64 + idx % 64
+// -- groups of 64 blocks, transposed.  A wave = 64 blocks of a scan (runs of consecutive blocks of one component) then reads or
+// writes dword j of all its blocks as a few contiguous segments instead of 64 different 128-byte lines.
+__host__ __device__ __forceinline__ size_t coef_word(long long idx, int j) { return ((size_t)(idx >> 6) * 32 + j) * 64 + (size_t)(idx & 63); }
+
 // ------------------------------------------------------------------ pass 1: colour conversion + FDCT + quantisation
 __device__ __forceinline__ void fdct8(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5, float& d6, float& d7) {
   const float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
@@ -99,7 +104,7 @@ template <int SUB> struct Tile {
 };
 
 template <int SUB>
-__global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restrict__ img, int16_t* __restrict__ coef, Geo g, Quant qt) {
+__global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ coef, Geo g, Quant qt) {
   using T = Tile<SUB>;
   extern __shared__ int16_t jl[];
   int16_t* sY = jl;
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restric
   const bool bgr = g.bgr != 0;
 
   // ---- stage: groups of four pixels
+#pragma unroll 4
   for (int i = threadIdx.x; i < 8 * (T::TPX / 4); i += 256) {
     const int r = i / (T::TPX / 4), gx = i - r * (T::TPX / 4);
     const int px0 = x_tile + gx * 4;
@@ -199,9 +205,9 @@ __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restric
     if (k & 1) packed[k >> 1] |= u << 16;
     else packed[k >> 1] = u;
   }
-  uint4* dst = reinterpret_cast<uint4*>(coef + ((size_t)g.coff[c] + (size_t)my * g.nbx[c] + bx) * 64);
+  const long long idx = g.coff[c] + (long long)my * g.nbx[c] + bx;
 #pragma unroll
-  for (int k = 0; k < 8; k++) dst[k] = make_uint4(packed[4 * k], packed[4 * k + 1], packed[4 * k + 2], packed[4 * k + 3]);
+  for (int j = 0; j < 32; j++) coef[coef_word(idx, j)] = packed[j];
 }
 
 // ------------------------------------------------------------------ passes 2 - 4: the block walk
@@ -264,15 +270,25 @@ __device__ __forceinline__ void locate(const Geo& g, const ScanDesc& sc, long lo
 
 // tabs: [dc0, dc1, ac0, ac1][256] = code << 8 | length.  hist: the same four tables of counts.
 template <int MODE>
-__global__ __launch_bounds__(256) void jpeg_code_kernel(const int16_t* __restrict__ coef, Geo g, ScanDesc sc, uint32_t* __restrict__ hist,
+__global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restrict__ coef, Geo g, ScanDesc sc, uint32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ tabs, uint16_t* __restrict__ lens,
                                                          uint32_t* __restrict__ wgsum, const uint64_t* __restrict__ wgoff, uint32_t* __restrict__ raw) {
-  __shared__ uint32_t lt[4 * 256];
+  // HIST: eight copies of the four histograms, a lane counts into copy (lane & 7); the copies start 1025 words apart, so the same
+  // symbol in different copies sits in different banks (most lanes of a wave emit one of a handful of symbols: with one copy the
+  // LDS atomics of a wave instruction serialise on those few addresses)
+  constexpr int COPIES = MODE == HIST ? 8 : 1, CSTRIDE = 1025;
+  __shared__ uint32_t lt[MODE == HIST ? COPIES * CSTRIDE : 1024];
   __shared__ uint32_t wsum[4];
-  for (int i = threadIdx.x; i < 1024; i += 256) lt[i] = MODE == HIST ? 0u : tabs[i];
+  if (MODE == HIST) for (int i = threadIdx.x; i < COPIES * CSTRIDE; i += 256) lt[i] = 0u;
+  else for (int i = threadIdx.x; i < 1024; i += 256) lt[i] = tabs[i];
   __syncthreads();
+  const int copy_base = MODE == HIST ? (int)(threadIdx.x & (COPIES - 1)) * CSTRIDE : 0;
 
-  const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  // HIST runs a fixed grid over all chunks of 256 blocks (fewer workgroups = fewer same-address global atomics when the LDS
+  // histograms are flushed); LEN and WRITE run one workgroup per chunk (their prefix sums are per chunk)
+  const long long nchunks = (sc.nscan + 255) / 256;
+  for (long long chunk = blockIdx.x; chunk < nchunks; chunk += (MODE == HIST ? (long long)gridDim.x : nchunks)) {
+  const long long s = chunk * 256 + threadIdx.x;
   const bool live = s < sc.nscan;
   uint32_t nbits_total = 0;
   BitWriter bw;
@@ -297,23 +313,22 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const int16_t* __restric
     long long idx, prev;
     locate(g, sc, s, c, idx, prev);
     const int tb = c ? 1 : 0;
-    const uint4* p = reinterpret_cast<const uint4*>(coef + (size_t)idx * 64);
     uint32_t w[32];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const uint4 v = p[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    for (int j = 0; j < 32; j++) w[j] = coef[coef_word(idx, j)];
 
     auto emit = [&](int table, int sym, uint32_t extra, int nextra) {
-      if (MODE == HIST) atomicAdd(&lt[table * 256 + sym], 1u);
+      if (MODE == HIST) atomicAdd(&lt[copy_base + table * 256 + sym], 1u);
       else {
         const uint32_t e = lt[table * 256 + sym];
         if (MODE == LEN) nbits_total += (e & 255u) + nextra;
-        else { bw.put(e >> 8, (int)(e & 255u)); if (nextra) bw.put(extra, nextra); }
+        else bw.put(((e >> 8) << nextra) | extra, (int)(e & 255u) + nextra);   // code and amplitude bits in one go: <= 16 + 11 bits
       }
     };
 
     if (sc.ss == 0) {
       const int dc = (int)(int16_t)(w[0] & 0xffffu);
-      const int pred = prev < 0 ? 0 : (int)coef[(size_t)prev * 64];
+      const int pred = prev < 0 ? 0 : (int)(int16_t)(coef[coef_word(prev, 0)] & 0xffffu);
       const int diff = dc - pred, sz = nbits_of(diff);
       emit(tb, sz, (uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << sz) - 1u), sz);
     }
@@ -334,10 +349,8 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const int16_t* __restric
     }
   }
 
-  if (MODE == HIST) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 1024; i += 256) if (lt[i]) atomicAdd(hist + i, lt[i]);
-  } else if (MODE == LEN) {
+  if (MODE == HIST) continue;
+  if (MODE == LEN) {
     if (live) lens[s] = (uint16_t)nbits_total;
     uint32_t v = nbits_total;
 #pragma unroll
@@ -354,6 +367,16 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const int16_t* __restric
       bw.finish();
     }
   }
+  }  // chunks
+  if (MODE == HIST) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int c = 0; c < COPIES; c++) v += lt[c * CSTRIDE + i];
+      if (v) atomicAdd(hist + i, v);
+    }
+  }
 }
 
 // device-side scalars of a scan
@@ -365,8 +388,9 @@ struct Scal {
 
 // exclusive prefix sum of n uint32 (n from the host, or from *n_dev) into uint64 out[0..n]; one workgroup of 1024.
 // what: 0 = block lengths -> total_bits / nbytes / nchunks, 1 = 0xFF counts -> total_ff / seg_len
+// what = 1 also closes the stream behind this segment with EOI (the markers of a following scan overwrite it)
 __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n_host,
-                                                          Scal* __restrict__ sc, int what) {
+                                                          Scal* __restrict__ sc, int what, uint8_t* __restrict__ segment, unsigned long long room) {
   __shared__ uint64_t wtot[16];
   __shared__ uint64_t carry_s;
   const uint32_t n = what == 0 ? n_host : sc->nchunks;
@@ -399,7 +423,10 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restr
       sc->nchunks = (sc->nbytes + 4095u) >> 12;
     } else {
       sc->total_ff = (unsigned int)carry_s;
-      sc->seg_len = (unsigned long long)sc->nbytes + carry_s;
+      const unsigned long long seg = (unsigned long long)sc->nbytes + carry_s;
+      sc->seg_len = seg;
+      if (seg + 2 <= room) { segment[seg] = 0xff; segment[seg + 1] = 0xd9; }
+      else sc->overflow = 1u;
     }
   }
 }
@@ -584,7 +611,7 @@ Layout make_layout(const Geo& g) {
   L.raw_cap = tdk_align_up((size_t)g.nblocks * MAX_BLOCK_BYTES + 64, 4096);
   L.nchunk_cap = L.raw_cap / 4096 + 1;
   L.stream_cap = HEADER_CAP + L.raw_cap;
-  L.coef = take((size_t)g.nblocks * 128);
+  L.coef = take((size_t)tdk_div_up64(g.nblocks, 64) * 64 * 128);
   L.lens = take((size_t)g.nblocks * 2);
   L.wgsum = take(L.nwg * 4);
   L.wgoff = take((L.nwg + 1) * 8);
@@ -599,7 +626,7 @@ Layout make_layout(const Geo& g) {
   return L;
 }
 
-template <int SUB> int launch_fdct(const uint8_t* img, int16_t* coef, const Geo& g, const Quant& q, hipStream_t st) {
+template <int SUB> int launch_fdct(const uint8_t* img, uint32_t* coef, const Geo& g, const Quant& q, hipStream_t st) {
   using T = Tile<SUB>;
   const dim3 grid((unsigned)tdk_div_up(g.nmcux * 8 * g.hs0, T::TPX), (unsigned)g.nmcuy);
   TDK_LAUNCH("tdk_jpeg(fdct)", (jpeg_fdct_kernel<SUB>), grid, dim3(256), (size_t)T::LDS_BYTES, st, img, coef, g, q);
@@ -627,7 +654,7 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
   make_geo(width, height, input_format, subsampling, g);
   const Layout L = make_layout(g);
   uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
-  int16_t* coef = reinterpret_cast<int16_t*>(ws + L.coef);
+  uint32_t* coef = reinterpret_cast<uint32_t*>(ws + L.coef);
   uint16_t* lens = reinterpret_cast<uint16_t*>(ws + L.lens);
   uint32_t* wgsum = reinterpret_cast<uint32_t*>(ws + L.wgsum);
   uint64_t* wgoff = reinterpret_cast<uint64_t*>(ws + L.wgoff);
@@ -690,7 +717,8 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
     const unsigned nwg = (unsigned)tdk_div_up64(sc.nscan, 256);
 
     TDK_HIP_CALL(hipMemsetAsync(hist, 0, 4096, st), "tdk_jpeg_encode: memset");
-    TDK_LAUNCH("tdk_jpeg(histogram)", (jpeg_code_kernel<HIST>), dim3(nwg), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
+    const unsigned nhist = nwg < (unsigned)(persistent / 2) ? nwg : (unsigned)(persistent / 2);
+    TDK_LAUNCH("tdk_jpeg(histogram)", (jpeg_code_kernel<HIST>), dim3(nhist), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
     uint32_t hh[1024];
     TDK_HIP_CALL(hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, st), "tdk_jpeg_encode: histogram copy");
     if (si > 0) TDK_HIP_CALL(hipMemcpyAsync(&hs, scal, sizeof hs, hipMemcpyDeviceToHost, st), "tdk_jpeg_encode: length copy");
@@ -726,12 +754,12 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
     TDK_HIP_CALL(hipMemcpyAsync(tabs, packed.data(), 4096, hipMemcpyHostToDevice, st), "tdk_jpeg_encode: table copy");
 
     TDK_LAUNCH("tdk_jpeg(lengths)", (jpeg_code_kernel<LEN>), dim3(nwg), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
-    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, wgsum, wgoff, (uint32_t)nwg, scal, 0);
+    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, wgsum, wgoff, (uint32_t)nwg, scal, 0, out, 0ull);
     TDK_LAUNCH("tdk_jpeg(zero)", jpeg_zero_kernel, dim3((unsigned)persistent), dim3(256), 0, st, raw, scal);
     TDK_LAUNCH("tdk_jpeg(write)", (jpeg_code_kernel<WRITE>), dim3(nwg), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
     TDK_LAUNCH("tdk_jpeg(count ff)", (jpeg_stuff_kernel<false>), dim3((unsigned)persistent), dim3(256), 0, st, raw, scal, ffcnt, ffoff, out,
                (unsigned long long)pos, (unsigned long long)(L.stream_cap - 2), scal);
-    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, ffcnt, ffoff, 0u, scal, 1);
+    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, ffcnt, ffoff, 0u, scal, 1, out + pos, (unsigned long long)(L.stream_cap - pos));
     TDK_LAUNCH("tdk_jpeg(stuff)", (jpeg_stuff_kernel<true>), dim3((unsigned)persistent), dim3(256), 0, st, raw, scal, ffcnt, ffoff, out,
                (unsigned long long)pos, (unsigned long long)(L.stream_cap - 2), scal);
   }
@@ -739,10 +767,7 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
   TDK_HIP_CALL(hipStreamSynchronize(st), "tdk_jpeg_encode: synchronize");
   TDK_REQUIRE(!hs.overflow, "tdk_jpeg_encode: stream larger than the workspace");
   pos += (size_t)hs.seg_len;
-  const uint8_t eoi[2] = {0xff, 0xd9};
-  TDK_HIP_CALL(hipMemcpyAsync(out + pos, eoi, 2, hipMemcpyHostToDevice, st), "tdk_jpeg_encode: trailer copy");
-  TDK_HIP_CALL(hipStreamSynchronize(st), "tdk_jpeg_encode: synchronize");
-  *length = pos + 2;
+  *length = pos + 2;  // EOI is already there (jpeg_scan_kernel)
   return TDK_OK;
 }
 
@@ -767,7 +792,15 @@ TDK_EXPORT int tdk_jpeg_coefficients(const void* workspace, int width, int heigh
   make_geo(width, height, 3, subsampling, g);
   const Layout L = make_layout(g);
   hipStream_t st = tdk_stream(stream);
-  TDK_HIP_CALL(hipMemcpyAsync(out_host, reinterpret_cast<const uint8_t*>(workspace) + L.coef, (size_t)g.nblocks * 128, hipMemcpyDeviceToHost, st), "tdk_jpeg_coefficients: copy");
+  const size_t nwords = (size_t)tdk_div_up64(g.nblocks, 64) * 64 * 32;
+  std::vector<uint32_t> tmp(nwords);
+  TDK_HIP_CALL(hipMemcpyAsync(tmp.data(), reinterpret_cast<const uint8_t*>(workspace) + L.coef, nwords * 4, hipMemcpyDeviceToHost, st), "tdk_jpeg_coefficients: copy");
   TDK_HIP_CALL(hipStreamSynchronize(st), "tdk_jpeg_coefficients: synchronize");
+  for (long long idx = 0; idx < g.nblocks; idx++)
+    for (int j = 0; j < 32; j++) {
+      const uint32_t v = tmp[coef_word(idx, j)];
+      out_host[idx * 64 + 2 * j] = (int16_t)(v & 0xffffu);
+      out_host[idx * 64 + 2 * j + 1] = (int16_t)(v >> 16);
+    }
   return TDK_OK;
 }
