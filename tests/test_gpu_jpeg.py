@@ -116,3 +116,21 @@ def test_tonemap_output_feeds_the_encoder_12mp(td, oracle, dev):
     ref = np.asarray(Image.open(io.BytesIO(buf.getvalue()))).astype(np.float64)
     mse_ours, mse_ref = np.mean((dec - src) ** 2), np.mean((ref - src) ** 2)
     assert mse_ours <= mse_ref * 1.02 and len(data) <= len(buf.getvalue()) * 1.01, (mse_ours, mse_ref, len(data), len(buf.getvalue()))
+
+
+def test_side_stream_and_50mp(td, oracle, dev):
+    """The coder works on PyTorch's current stream (the reference: at::cuda::getCurrentCUDAStream, jpeg_encoder.cu:156) -- here a side
+    stream whose producer is still running -- and at BASELINE config 5's frame size (8192 x 6144: 1.57 M blocks, 0.87 GB of workspace)."""
+    from torch_darktable.synthetic import synthetic_rgb
+
+    h, w = 6144, 8192
+    side = torch.cuda.Stream(device=dev)
+    rgb = synthetic_rgb(h, w, 9, dev, 0.01)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        u8 = td.aces_tonemap(rgb, td.TonemapParameters(1.0, 0.0, 0.8, 0.0))   # producer on the same side stream, not synchronised
+        data = td.Jpeg().encode(u8, 90, td.InputFormat.RGBI, td.Subsampling.CSS_422, False).numpy()
+    side.synchronize()
+    want = oracle.jpeg_encode(u8.cpu().numpy(), 90, 3, 1, False)
+    assert data.shape == want.shape and np.array_equal(data, want)
+    assert decode(data).size == (w, h)
