@@ -117,11 +117,18 @@ size_t tdk_postprocess_workspace_bytes(int width, int height, int color_smoothin
 int tdk_postprocess(const float* rgb_in, float* rgb_out, void* workspace, int width, int height, uint32_t pattern,
                     int color_smoothing_passes, int green_eq_local, int green_eq_global, float green_eq_threshold,
                     tdk_stream_t stream);
+/* The same with the storage type of rgb_in / rgb_out as `dtype` (TDK_F16: an extension; the reference is float32-only).  The images
+ * between the stages of a call stay fp32 in the workspace, so a binary16 result is the fp32 result rounded once. */
+size_t tdk_postprocess_workspace_bytes_ex(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global, int dtype);
+int tdk_postprocess_ex(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, uint32_t pattern, int color_smoothing_passes,
+                       int green_eq_local, int green_eq_global, float green_eq_threshold, int dtype, tdk_stream_t stream);
 
 /* apply_white_balance: reference csrc/white_balance.cu:164-183 (extension.cpp:209-210).
  * gains: 3 floats on the DEVICE (no host read-back). out may alias in. */
 int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float* gains, int width, int height, uint32_t pattern,
                             tdk_stream_t stream);
+int tdk_apply_white_balance_ex(const void* bayer_in, void* bayer_out, const float* gains, int width, int height, uint32_t pattern, int dtype,
+                               tdk_stream_t stream); /* dtype: storage type of the mosaic (TDK_F16: extension) */
 
 /* estimate_white_balance, sample collection: reference csrc/white_balance.cu:57-126 (collect_samples;
  * extension.cpp:211-212).  One sample per cell of the (height/stride) x (width/stride) grid, n = sh * sw:
@@ -132,6 +139,8 @@ int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float
  * binding's device ops, as in the reference.  bayer: (H, W) float32. */
 int tdk_wb_collect_samples(const float* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
                            float* intensity, uint8_t* mask, tdk_stream_t stream);
+int tdk_wb_collect_samples_ex(const void* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
+                              float* intensity, uint8_t* mask, int dtype, tdk_stream_t stream); /* dtype: storage type of the mosaic; the samples stay fp32 */
 
 /* ---- colour operators: reference csrc/color_conversions.cu (extension.cpp:127-156).
  * (H, W, 3) -> (H, W, 3), npix = H * W. */
@@ -143,6 +152,8 @@ enum tdk_color_op {
 };
 int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
                  tdk_stream_t stream);
+int tdk_color_op_ex(const void* in, void* out, int64_t npix, int op, const float host_params[3], const float* device_matrix, int dtype,
+                    tdk_stream_t stream); /* dtype: storage type of in and out (TDK_F16: extension; fp32 arithmetic, rounded once) */
 
 /* compute_luminance / compute_log_luminance: color_conversions.cu:226-233.  rgb (H,W,3) -> lum (H,W) */
 int tdk_compute_luminance(const void* rgb, void* lum, int64_t npix, int log_mode, float eps, int rgb_dtype, int lum_dtype,
@@ -269,6 +280,10 @@ int tdk_bilateral_lab(const float* lum_in, const float* ab_in, void* rgb_out, vo
 size_t tdk_laplacian_workspace_bytes(int width, int height, int num_gamma);
 int tdk_laplacian(const float* lum_in, float* lum_out, void* workspace, int width, int height, int num_gamma, float sigma,
                   float shadows, float highlights, float clarity, tdk_stream_t stream);
+/* dtype: storage type of lum_in / lum_out.  The reference pads the image to binary16 and writes binary16 values back as float32
+ * (laplacian.cu:70-108): a binary16 image in and out carries the SAME values, nothing is rounded twice. */
+int tdk_laplacian_ex(const void* lum_in, void* lum_out, void* workspace, int width, int height, int num_gamma, float sigma, float shadows,
+                     float highlights, float clarity, int dtype, tdk_stream_t stream);
 
 /* ---- Jpeg.encode: reference csrc/jpeg_encoder.cu:104-180 (extension.cpp:226-246), an nvjpeg wrapper: nvjpegEncodeImage with
  * quality, optimised Huffman tables, sampling factors 444 / 422 / GRAY, baseline or progressive, then

@@ -37,7 +37,7 @@ inline int stream_grid(int64_t nthreads) {
   return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
-template <int OP> __global__ __launch_bounds__(256) void color_vec4(const float* __restrict__ in, float* __restrict__ out, int64_t ngroups, OpArgs a) {
+template <int OP, typename T> __global__ __launch_bounds__(256) void color_vec4(const T* __restrict__ in, T* __restrict__ out, int64_t ngroups, OpArgs a) {
   float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (OP == TDK_TRANSFORM_3X3) {
 #pragma unroll
@@ -45,39 +45,43 @@ template <int OP> __global__ __launch_bounds__(256) void color_vec4(const float*
   }
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
     float v[12];
-    rgb4_io<float>::load(in, g, v);
+    rgb4_io<T>::load(in, g, v);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const f3 r = apply_op<OP>(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]), a, m);
       v[3 * k] = r.x; v[3 * k + 1] = r.y; v[3 * k + 2] = r.z;
     }
-    rgb4_io<float>::store(out, g, v);
+    rgb4_io<T>::store(out, g, v);
   }
 }
 
-template <int OP> __global__ __launch_bounds__(256) void color_tail(const float* __restrict__ in, float* __restrict__ out, int64_t first, int64_t npix, OpArgs a) {
+template <int OP, typename T> __global__ __launch_bounds__(256) void color_tail(const T* __restrict__ in, T* __restrict__ out, int64_t first, int64_t npix, OpArgs a) {
   float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (OP == TDK_TRANSFORM_3X3) {
 #pragma unroll
     for (int k = 0; k < 9; k++) m[k] = a.matrix[k];
   }
   for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
-    const f3 r = apply_op<OP>(mk3(in[3 * i], in[3 * i + 1], in[3 * i + 2]), a, m);
-    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    const f3 r = apply_op<OP>(mk3(ld<T>(in, 3 * i), ld<T>(in, 3 * i + 1), ld<T>(in, 3 * i + 2)), a, m);
+    st<T>(out, 3 * i, r.x); st<T>(out, 3 * i + 1, r.y); st<T>(out, 3 * i + 2, r.z);
   }
 }
 
-template <int OP> int run_color(const float* in, float* out, int64_t npix, OpArgs a, hipStream_t s) {
+template <int OP, typename T> int run_color_t(const T* in, T* out, int64_t npix, OpArgs a, hipStream_t s) {
   int64_t done = 0;
-  if (tdk_aligned(in, 16) && tdk_aligned(out, 16) && npix >= 4) {
+  if (tdk_aligned(in, 4 * sizeof(T)) && tdk_aligned(out, 4 * sizeof(T)) && npix >= 4) {
     const int64_t ng = npix / 4;
-    TDK_LAUNCH("tdk_color_op", color_vec4<OP>, dim3(stream_grid(ng)), dim3(256), 0, s, in, out, ng, a);
+    TDK_LAUNCH("tdk_color_op", (color_vec4<OP, T>), dim3(stream_grid(ng)), dim3(256), 0, s, in, out, ng, a);
     done = ng * 4;
   }
   if (done < npix) {
-    TDK_LAUNCH("tdk_color_op", color_tail<OP>, dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, a);
+    TDK_LAUNCH("tdk_color_op", (color_tail<OP, T>), dim3(stream_grid(npix - done)), dim3(256), 0, s, in, out, done, npix, a);
   }
   return TDK_OK;
+}
+template <int OP> int run_color(const void* in, void* out, int64_t npix, OpArgs a, int dtype, hipStream_t s) {
+  if (dtype == TDK_F16) return run_color_t<OP, __half>(reinterpret_cast<const __half*>(in), reinterpret_cast<__half*>(out), npix, a, s);
+  return run_color_t<OP, float>(reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), npix, a, s);
 }
 
 // ---- luminance extract: rgb (T_RGB) -> plane (T_L)
@@ -229,28 +233,34 @@ __global__ __launch_bounds__(256) void normalize_kernel(const T* __restrict__ in
 
 }  // namespace
 
-TDK_EXPORT int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
-                            tdk_stream_t stream) {
+TDK_EXPORT int tdk_color_op_ex(const void* in, void* out, int64_t npix, int op, const float host_params[3], const float* device_matrix, int dtype,
+                               tdk_stream_t stream) {
   TDK_REQUIRE(npix >= 0, "tdk_color_op: negative pixel count");
+  TDK_REQUIRE(dtype == TDK_F32 || dtype == TDK_F16, "unsupported dtype tag %d", dtype);
   if (npix == 0) return TDK_OK;
   TDK_REQUIRE(in && out, "tdk_color_op: null pointer");
   OpArgs a{0.0f, 0.0f, 0.0f, device_matrix};
   if (host_params) { a.p0 = host_params[0]; a.p1 = host_params[1]; a.p2 = host_params[2]; }
   hipStream_t s = tdk_stream(stream);
   switch (op) {
-    case TDK_RGB_TO_XYZ: return run_color<TDK_RGB_TO_XYZ>(in, out, npix, a, s);
-    case TDK_XYZ_TO_LAB: return run_color<TDK_XYZ_TO_LAB>(in, out, npix, a, s);
-    case TDK_LAB_TO_XYZ: return run_color<TDK_LAB_TO_XYZ>(in, out, npix, a, s);
-    case TDK_XYZ_TO_RGB: return run_color<TDK_XYZ_TO_RGB>(in, out, npix, a, s);
-    case TDK_RGB_TO_LAB: return run_color<TDK_RGB_TO_LAB>(in, out, npix, a, s);
-    case TDK_LAB_TO_RGB: return run_color<TDK_LAB_TO_RGB>(in, out, npix, a, s);
-    case TDK_MODIFY_HSL: return run_color<TDK_MODIFY_HSL>(in, out, npix, a, s);
-    case TDK_MODIFY_VIBRANCE: return run_color<TDK_MODIFY_VIBRANCE>(in, out, npix, a, s);
+    case TDK_RGB_TO_XYZ: return run_color<TDK_RGB_TO_XYZ>(in, out, npix, a, dtype, s);
+    case TDK_XYZ_TO_LAB: return run_color<TDK_XYZ_TO_LAB>(in, out, npix, a, dtype, s);
+    case TDK_LAB_TO_XYZ: return run_color<TDK_LAB_TO_XYZ>(in, out, npix, a, dtype, s);
+    case TDK_XYZ_TO_RGB: return run_color<TDK_XYZ_TO_RGB>(in, out, npix, a, dtype, s);
+    case TDK_RGB_TO_LAB: return run_color<TDK_RGB_TO_LAB>(in, out, npix, a, dtype, s);
+    case TDK_LAB_TO_RGB: return run_color<TDK_LAB_TO_RGB>(in, out, npix, a, dtype, s);
+    case TDK_MODIFY_HSL: return run_color<TDK_MODIFY_HSL>(in, out, npix, a, dtype, s);
+    case TDK_MODIFY_VIBRANCE: return run_color<TDK_MODIFY_VIBRANCE>(in, out, npix, a, dtype, s);
     case TDK_TRANSFORM_3X3:
       TDK_REQUIRE(device_matrix != nullptr, "tdk_color_op: TDK_TRANSFORM_3X3 needs a device matrix");
-      return run_color<TDK_TRANSFORM_3X3>(in, out, npix, a, s);
+      return run_color<TDK_TRANSFORM_3X3>(in, out, npix, a, dtype, s);
     default: tdk_set_error("tdk_color_op: unknown op %d", op); return TDK_ERR_INVALID_ARGUMENT;
   }
+}
+
+TDK_EXPORT int tdk_color_op(const float* in, float* out, int64_t npix, int op, const float host_params[3], const float* device_matrix,
+                            tdk_stream_t stream) {
+  return tdk_color_op_ex(in, out, npix, op, host_params, device_matrix, TDK_F32, stream);
 }
 
 #define TDK_LUM_DISPATCH(FN, ...)                                                                    \

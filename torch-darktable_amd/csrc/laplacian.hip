@@ -65,9 +65,9 @@ struct Layout {
 };
 
 // binary16(padded input) at padded coordinates (pad_input_half, laplacian.cu:70-90)
-__device__ __forceinline__ float padded0(const float* __restrict__ in, const Layout& L, int x, int y) {
+template <typename T> __device__ __forceinline__ float padded0(const T* __restrict__ in, const Layout& L, int x, int y) {
   const int cx = min(max(x - L.pad, 0), L.w - 1), cy = min(max(y - L.pad, 0), L.h - 1);
-  return round_half(in[(size_t)cy * L.w + cx]);
+  return round_half(ld<T>(in, (size_t)cy * L.w + cx));  // binary16 storage: the value itself
 }
 
 __device__ __forceinline__ int clampc(int p, int n) {  // the reduce's centre clamp (laplacian.cu:185-190)
@@ -172,8 +172,8 @@ __device__ __forceinline__ float gamma_centre(int k) { return ((float)k + 0.5f) 
 // through the same index map, i.e. runs the same arithmetic on the same values as the full window would.
 constexpr int A_TW = 32, A_TH = 16, A_FW = 2 * A_TW + 3, A_FH = 2 * A_TH + 3, A_FS = A_FW + 1, A_NT = 512;
 
-template <bool HAS_CLARITY>
-__global__ __launch_bounds__(A_NT) void level1_kernel(const float* __restrict__ in, Layout L, float sigma, float shadows, float highlights, float clarity) {
+template <bool HAS_CLARITY, typename T>
+__global__ __launch_bounds__(A_NT) void level1_kernel(const T* __restrict__ in, Layout L, float sigma, float shadows, float highlights, float clarity) {
   __shared__ __half fine[NP][A_FH * A_FS];
   const CurveK ck = make_curve(sigma, shadows, highlights, clarity);
   const int cw = L.lw(1), ch = L.lh(1);
@@ -387,8 +387,8 @@ __device__ __forceinline__ float assemble_px(float v, int qx, int qy, OC out_c, 
 // (write_back_half, laplacian.cu:92-108) for the pixels inside the image.
 constexpr int ATW = 64, ATH = 16, ACW = ATW / 2 + 3, ACH = ATH / 2 + 3, ACS = ACW + 1;
 
-template <bool LEVEL0, bool HAS_CLARITY>
-__global__ __launch_bounds__(256) void assemble_tiled_kernel(Layout L, int l, const float* __restrict__ image, float* __restrict__ result, float sigma,
+template <bool LEVEL0, bool HAS_CLARITY, typename T>
+__global__ __launch_bounds__(256) void assemble_tiled_kernel(Layout L, int l, const T* __restrict__ image, T* __restrict__ result, float sigma,
                                                              float shadows, float highlights, float clarity, int tile_x0, int tile_y0) {
   __shared__ float tiles[NP * ACH * ACS];
   const CurveK ck = make_curve(sigma, shadows, highlights, clarity);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void assemble_tiled_kernel(Layout L, int l, co
     // index clamps only matter for taps of weight 0
     auto tile = [&](int k, int i, int j) { return tiles[k * (ACH * ACS) + max(j - ty0, 0) * ACS + max(i - tx0, 0)]; };
     float v;
-    if constexpr (LEVEL0) v = round_half(image[(size_t)(y - L.pad) * L.w + (x - L.pad)]);
+    if constexpr (LEVEL0) v = round_half(ld<T>(image, (size_t)(y - L.pad) * L.w + (x - L.pad)));
     else v = hld(L.at(0, l), x, y, fw);
     const float val = assemble_px(
         v, qx, qy, [&](int i, int j) { return tile(0, i, j); }, [&](int k, int i, int j) { return tile(1 + k, i, j); },
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void assemble_tiled_kernel(Layout L, int l, co
           if constexpr (LEVEL0) return round_half(curve<HAS_CLARITY>(v, gamma_centre(k), ck));
           else return hld(L.at(2 + k, l), x, y, fw);
         });
-    if constexpr (LEVEL0) result[(size_t)(y - L.pad) * L.w + (x - L.pad)] = round_half(val);
+    if constexpr (LEVEL0) st<T>(result, (size_t)(y - L.pad) * L.w + (x - L.pad), round_half(val));
     else hst(L.at(1, l), x, y, fw, val);
   }
 }
@@ -495,8 +495,10 @@ TDK_EXPORT size_t tdk_laplacian_workspace_bytes(int width, int height, int num_g
   return tdk_align_up((size_t)(2 + NG) * L.pyr_elems * sizeof(__half), 256);  // padded + output + 6 gamma pyramids, levels >= 1
 }
 
-TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspace, int width, int height, int num_gamma, float sigma,
-                             float shadows, float highlights, float clarity, tdk_stream_t stream) {
+namespace {
+template <typename T>
+int laplacian_t(const T* lum_in, T* lum_out, void* workspace, int width, int height, int num_gamma, float sigma, float shadows, float highlights,
+                float clarity, tdk_stream_t stream) {
   TDK_REQUIRE(num_gamma == NG, "Unsupported gamma count: %d", num_gamma);
   TDK_REQUIRE(lum_in && lum_out && workspace, "tdk_laplacian: null pointer");
   TDK_REQUIRE(width >= 4 && height >= 4, "tdk_laplacian: image %dx%d too small", width, height);
@@ -508,8 +510,8 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
 
   // ---- reduce side: level 1 of the seven pyramids, then pairs of levels, then everything small in one launch
   const dim3 g1(tdk_div_up(L.lw(1), A_TW), tdk_div_up(L.lh(1), A_TH));
-  if (clarity != 0.0f) TDK_LAUNCH("tdk_laplacian(level1)", level1_kernel<true>, g1, dim3(A_NT), 0, s, lum_in, L, sigma, shadows, highlights, clarity);
-  else TDK_LAUNCH("tdk_laplacian(level1)", level1_kernel<false>, g1, dim3(A_NT), 0, s, lum_in, L, sigma, shadows, highlights, clarity);
+  if (clarity != 0.0f) TDK_LAUNCH("tdk_laplacian(level1)", (level1_kernel<true, T>), g1, dim3(A_NT), 0, s, lum_in, L, sigma, shadows, highlights, clarity);
+  else TDK_LAUNCH("tdk_laplacian(level1)", (level1_kernel<false, T>), g1, dim3(A_NT), 0, s, lum_in, L, sigma, shadows, highlights, clarity);
   int l = 1;  // finest level that exists so far
   while (l < top && !small(l + 1)) {
     if (l + 2 <= top) {  // also when level l + 2 is already small: it costs less here than as the single-workgroup kernel's first level
@@ -550,12 +552,30 @@ TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspac
     const int tx0 = rc.x0 / ATW, tx1 = rc.x1 / ATW, ty0 = rc.y0 / ATH, ty1 = rc.y1 / ATH;
     const dim3 g(tx1 - tx0 + 1, ty1 - ty0 + 1);
     if (a == 0 && clarity != 0.0f)
-      TDK_LAUNCH("tdk_laplacian(assemble 0)", (assemble_tiled_kernel<true, true>), g, dim3(256), 0, s, L, a, lum_in, lum_out, sigma, shadows, highlights, clarity, tx0, ty0);
+      TDK_LAUNCH("tdk_laplacian(assemble 0)", (assemble_tiled_kernel<true, true, T>), g, dim3(256), 0, s, L, a, lum_in, lum_out, sigma, shadows, highlights, clarity, tx0, ty0);
     else if (a == 0)
-      TDK_LAUNCH("tdk_laplacian(assemble 0)", (assemble_tiled_kernel<true, false>), g, dim3(256), 0, s, L, a, lum_in, lum_out, sigma, shadows, highlights, clarity, tx0, ty0);
+      TDK_LAUNCH("tdk_laplacian(assemble 0)", (assemble_tiled_kernel<true, false, T>), g, dim3(256), 0, s, L, a, lum_in, lum_out, sigma, shadows, highlights, clarity, tx0, ty0);
     else
-      TDK_LAUNCH(a == 1 ? "tdk_laplacian(assemble 1)" : a == 2 ? "tdk_laplacian(assemble 2)" : "tdk_laplacian(assemble 3+)", (assemble_tiled_kernel<false, false>), g,
+      TDK_LAUNCH(a == 1 ? "tdk_laplacian(assemble 1)" : a == 2 ? "tdk_laplacian(assemble 2)" : "tdk_laplacian(assemble 3+)", (assemble_tiled_kernel<false, false, T>), g,
                  dim3(256), 0, s, L, a, lum_in, lum_out, sigma, shadows, highlights, clarity, tx0, ty0);
   }
   return TDK_OK;
+}
+}  // namespace
+
+/* dtype: storage type of lum_in and lum_out.  The reference pads the image to binary16 and writes binary16 values back as float32
+ * (laplacian.cu:70-108), so a binary16 image in and out is the SAME result, not a rounded one. */
+TDK_EXPORT int tdk_laplacian_ex(const void* lum_in, void* lum_out, void* workspace, int width, int height, int num_gamma, float sigma, float shadows,
+                                float highlights, float clarity, int dtype, tdk_stream_t stream) {
+  if (dtype == TDK_F16)
+    return laplacian_t<__half>(reinterpret_cast<const __half*>(lum_in), reinterpret_cast<__half*>(lum_out), workspace, width, height, num_gamma, sigma, shadows,
+                               highlights, clarity, stream);
+  TDK_REQUIRE(dtype == TDK_F32, "unsupported dtype tag %d", dtype);
+  return laplacian_t<float>(reinterpret_cast<const float*>(lum_in), reinterpret_cast<float*>(lum_out), workspace, width, height, num_gamma, sigma, shadows,
+                            highlights, clarity, stream);
+}
+
+TDK_EXPORT int tdk_laplacian(const float* lum_in, float* lum_out, void* workspace, int width, int height, int num_gamma, float sigma,
+                             float shadows, float highlights, float clarity, tdk_stream_t stream) {
+  return tdk_laplacian_ex(lum_in, lum_out, workspace, width, height, num_gamma, sigma, shadows, highlights, clarity, TDK_F32, stream);
 }

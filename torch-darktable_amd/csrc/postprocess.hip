@@ -34,6 +34,14 @@ __device__ __forceinline__ float median9(float s0, float s1, float s2, float s3,
   return med3f(lo, mid, hi);
 }
 
+// four consecutive values to storage type T at element index e (16 / 8-byte aligned)
+template <typename T> __device__ __forceinline__ void st4(T* p, size_t e, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, size_t e, float4 v) { *reinterpret_cast<float4*>(p + e) = v; }
+template <> __device__ __forceinline__ void st4<__half>(__half* p, size_t e, float4 v) {
+  const float q[4] = {v.x, v.y, v.z, v.w};
+  s4_io<__half>::store(p + e, 0, q);
+}
+
 constexpr int STW = 64, STH = 16, SNT = 512;  // tile and threads per workgroup: 36 KB of LDS -> 4 workgroups x 8 waves per CU
 
 // Up to FMAXP smoothing passes in ONE kernel: the tile + P-px halo is read once, the (R-G, B-G)
@@ -59,8 +67,10 @@ constexpr int FGR = FLW / 4;           // 18 four-pixel groups per staged row
 static_assert(FGR * FLH <= SNT, "staging: one group per thread");
 static_assert(2 * FPL >= STH * STW * 3, "the last pass's RGB tile fits two planes");
 
-// vec_in / vec_ok: width % 4 == 0 and `in` / `out` 16-byte aligned
-__global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height, int vec_in, int vec_ok,
+// vec_in / vec_ok: width % 4 == 0 and `in` / `out` aligned to four of their elements (16 bytes fp32, 8 bytes binary16).
+// TI / TO: storage types of `in` and `out` (fp32 between the stages of a call, the caller's type at its two ends)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const TI* __restrict__ in, TO* __restrict__ out, int width, int height, int vec_in, int vec_ok,
                                                               int passes) {
   __shared__ __align__(16) float lds[5 * FPL];  // G | DR0 | DB0 | DR1 | DB1
   float* G = lds;
@@ -79,15 +89,15 @@ __global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __res
       if (gy >= 0 && gy < height) {
         if (vec_in && gx >= 0 && gx + 4 <= width) {  // width % 4 == 0 and a 16-B aligned image: the group is three aligned 16-B loads
           float v[12];
-          rgb4_io<float>::load(in, ((size_t)gy * width + gx) >> 2, v);
+          rgb4_io<TI>::load(in, ((size_t)gy * width + gx) >> 2, v);
 #pragma unroll
           for (int k = 0; k < 4; k++) { g[k] = v[3 * k + 1]; a[k] = v[3 * k] - g[k]; b[k] = v[3 * k + 2] - g[k]; }
         } else {
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (gx + k >= 0 && gx + k < width) {
-              const float* p = in + ((size_t)gy * width + gx + k) * 3;
-              g[k] = p[1]; a[k] = p[0] - g[k]; b[k] = p[2] - g[k];
+              const size_t p = ((size_t)gy * width + gx + k) * 3;
+              g[k] = ld<TI>(in, p + 1); a[k] = ld<TI>(in, p) - g[k]; b[k] = ld<TI>(in, p + 2) - g[k];
             }
         }
       }
@@ -172,12 +182,12 @@ __global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __res
     if (vec_ok && cols == STW) {            // whole 16-B groups: 48 per row
       for (int i = tid; i < STH * (3 * STW / 4); i += SNT) {
         const int r = i / (3 * STW / 4), k = i - r * (3 * STW / 4);
-        if (y0 + r < height) *reinterpret_cast<float4*>(out + ((size_t)(y0 + r) * width + x0) * 3 + 4 * k) = *reinterpret_cast<const float4*>(tile + r * (3 * STW) + 4 * k);
+        if (y0 + r < height) st4<TO>(out, ((size_t)(y0 + r) * width + x0) * 3 + 4 * k, *reinterpret_cast<const float4*>(tile + r * (3 * STW) + 4 * k));
       }
     } else {
       for (int i = tid; i < STH * 3 * STW; i += SNT) {
         const int r = i / (3 * STW), f = i - r * (3 * STW);
-        if (y0 + r < height && f < 3 * cols) out[((size_t)(y0 + r) * width + x0) * 3 + f] = tile[r * (3 * STW) + f];
+        if (y0 + r < height && f < 3 * cols) st<TO>(out, ((size_t)(y0 + r) * width + x0) * 3 + f, tile[r * (3 * STW) + f]);
       }
     }
   }
@@ -187,7 +197,8 @@ __global__ __launch_bounds__(SNT) void smoothing_fused_kernel(const float* __res
 constexpr int GEQ_BLOCKS = 1024;
 
 // partial[b] = (sum G on even rows, sum G on odd rows) over x < 2*(W/2), y < 2*(H/2)
-__global__ __launch_bounds__(256) void green_sums_kernel(const float* __restrict__ in, int width, int height, uint32_t pattern,
+template <typename TI>
+__global__ __launch_bounds__(256) void green_sums_kernel(const TI* __restrict__ in, int width, int height, uint32_t pattern,
                                                          float2* __restrict__ partial) {
   __shared__ float s1[4], s2[4];
   const int we = 2 * (width / 2), he = 2 * (height / 2);
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void green_sums_kernel(const float* __restrict
   for (int y = blockIdx.x; y < he; y += gridDim.x)  // whole rows per workgroup: no index division
     for (int x = threadIdx.x; x < we; x += 256)
       if (cfa_color(y, x, pattern) == 1) {
-        const float g = in[((size_t)y * width + x) * 3 + 1];
+        const float g = ld<TI>(in, ((size_t)y * width + x) * 3 + 1);
         if (y & 1) b += g;
         else a += g;
       }
@@ -229,8 +240,8 @@ __global__ __launch_bounds__(256) void green_ratio_kernel(const float2* __restri
 // (VEC == 4: 48-B vector accesses; requires width % 4 == 0 and 16-B aligned images).
 
 // postprocess.cu:234-255
-template <int VEC>
-__global__ __launch_bounds__(256) void green_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
+template <int VEC, typename TI, typename TO>
+__global__ __launch_bounds__(256) void green_apply_kernel(const TI* __restrict__ in, TO* __restrict__ out, int width, int height,
                                                           uint32_t pattern, const float* __restrict__ ratio) {
   const float r = ratio[0];
   const int ngroup = width / VEC;
@@ -238,8 +249,8 @@ __global__ __launch_bounds__(256) void green_apply_kernel(const float* __restric
     for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroup; gi += gridDim.x * 256) {
       const size_t g4 = (size_t)y * ngroup + gi;
       float v[3 * VEC];
-      if constexpr (VEC == 4) rgb4_io<float>::load(in, g4, v);
-      else { v[0] = in[g4 * 3]; v[1] = in[g4 * 3 + 1]; v[2] = in[g4 * 3 + 2]; }
+      if constexpr (VEC == 4) rgb4_io<TI>::load(in, g4, v);
+      else { v[0] = ld<TI>(in, g4 * 3); v[1] = ld<TI>(in, g4 * 3 + 1); v[2] = ld<TI>(in, g4 * 3 + 2); }
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
         const bool g1 = (cfa_color(y, gi * VEC + k, pattern) == 1) && !(y & 1);
@@ -248,8 +259,8 @@ __global__ __launch_bounds__(256) void green_apply_kernel(const float* __restric
         v[3 * k + 1] = fmaxf(g, 0.0f);
         v[3 * k + 2] = fmaxf(v[3 * k + 2], 0.0f);
       }
-      if constexpr (VEC == 4) rgb4_io<float>::store(out, g4, v);
-      else { out[g4 * 3] = v[0]; out[g4 * 3 + 1] = v[1]; out[g4 * 3 + 2] = v[2]; }
+      if constexpr (VEC == 4) rgb4_io<TO>::store(out, g4, v);
+      else { st<TO>(out, g4 * 3, v[0]); st<TO>(out, g4 * 3 + 1, v[1]); st<TO>(out, g4 * 3 + 2, v[2]); }
     }
 }
 
@@ -267,13 +278,13 @@ constexpr int GLQ = (GLW + 8) / 4;       // 18 words per column class: the tile 
 constexpr int GLS = 80;                  // row stride
 __device__ __forceinline__ int gl_at(int r, int c) { return r * GLS + (c >> 2) + (c & 3) * GLQ; }  // r in [0, 20), c in [0, 72): image (y0 - 2 + r, x0 - 4 + c)
 
-template <int VEC>
-__global__ __launch_bounds__(256) void green_local_kernel(const float* __restrict__ in, float* __restrict__ out, int width, int height,
+template <int VEC, typename TI, typename TO>
+__global__ __launch_bounds__(256) void green_local_kernel(const TI* __restrict__ in, TO* __restrict__ out, int width, int height,
                                                           uint32_t pattern, float threshold) {
   __shared__ float gt[(GLH + 4) * GLS];
   const int x0 = blockIdx.x * GLW, y0 = blockIdx.y * GLH;
   const int tid = threadIdx.x;
-  auto green_at = [&](int gx, int gy) { return (gx >= 0 && gy >= 0 && gx < width && gy < height) ? in[((size_t)gy * width + gx) * 3 + 1] : 0.0f; };
+  auto green_at = [&](int gx, int gy) { return (gx >= 0 && gy >= 0 && gx < width && gy < height) ? ld<TI>(in, ((size_t)gy * width + gx) * 3 + 1) : 0.0f; };
   if constexpr (VEC == 4) {
     // own pixels: 16 threads x 4 px per row, 16 rows
     const int lx = (tid & 15) * 4, ly = tid >> 4;
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void green_local_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 12; k++) v[k] = 0.0f;
     const size_t p0 = (size_t)y * width + x;
-    if (live) rgb4_io<float>::load(in, p0 >> 2, v);
+    if (live) rgb4_io<TI>::load(in, p0 >> 2, v);
     // halo: rows y0 - 2, y0 - 1, y0 + 16, y0 + 17 over columns x0 - 2 .. x0 + 65 (4 x 68), then columns x0 - 2, x0 - 1, x0 + 64,
     // x0 + 65 of the 16 tile rows (16 x 4): 336 greens
     float hv[2];
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void green_local_kernel(const float* __restric
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) v[3 * k + 1] = fmaxf(v[3 * k + 1], 0.0f);
-    rgb4_io<float>::store(out, p0 >> 2, v);
+    rgb4_io<TO>::store(out, p0 >> 2, v);
   } else {
     // unaligned images: the scalar form (green tile gathered, then one pixel per thread)
     for (int i = tid; i < (GLW + 4) * (GLH + 4); i += 256) {
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void green_local_kernel(const float* __restric
       const int x = x0 + lx, y = y0 + ly;
       if (x >= width || y >= height) continue;
       const size_t p0 = (size_t)y * width + x;
-      float o = in[p0 * 3 + 1];
+      float o = ld<TI>(in, p0 * 3 + 1);
       if (cfa_color(y, x, pattern) == 1 && (y & 1)) {
         auto g = [&](int dy, int dx) { return gt[gl_at(ly + 2 + dy, lx + 4 + dx)]; };
         const float maximum = 1.0f;
@@ -361,15 +372,16 @@ __global__ __launch_bounds__(256) void green_local_kernel(const float* __restric
           if ((o < maximum * 0.95f) && (c1 < maximum * threshold) && (c2 < maximum * threshold)) o *= m1 / m2;
         }
       }
-      out[p0 * 3] = in[p0 * 3];
-      out[p0 * 3 + 1] = fmaxf(o, 0.0f);
-      out[p0 * 3 + 2] = in[p0 * 3 + 2];
+      st<TO>(out, p0 * 3, ld<TI>(in, p0 * 3));
+      st<TO>(out, p0 * 3 + 1, fmaxf(o, 0.0f));
+      st<TO>(out, p0 * 3 + 2, ld<TI>(in, p0 * 3 + 2));
     }
   }
 }
 
 // white_balance.cu:10-42
-__global__ __launch_bounds__(256) void white_balance_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ gains,
+template <typename T>
+__global__ __launch_bounds__(256) void white_balance_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ gains,
                                                             int width, int height, uint32_t pattern) {
   const float gr = gains[0], gg = gains[1], gb = gains[2];
   for (int y = blockIdx.y; y < height; y += gridDim.y)
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void white_balance_kernel(const float* __restr
       const int c = cfa_color(y, x, pattern);
       const float g = (c == 0) ? gr : (c == 2 ? gb : gg);
       const size_t i = (size_t)y * width + x;
-      out[i] = clampf(in[i] * g, 0.0f, 1.0f);
+      st<T>(out, i, clampf(ld<T>(in, i) * g, 0.0f, 1.0f));
     }
 }
 
@@ -390,75 +402,128 @@ inline int stream_grid(int64_t nthreads) {
 
 }  // namespace
 
-TDK_EXPORT size_t tdk_postprocess_workspace_bytes(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global) {
-  if (width <= 0 || height <= 0) return 0;
+namespace {
+struct Img {
+  void* p;
+  int dtype;
+  bool aligned4() const { return tdk_aligned(p, dtype == TDK_F16 ? 8 : 16); }
+};
+// TI / TO = the storage types of a stage's source and destination
+#define PP_TYPES(src_, dst_, ...)                                                                            \
+  do {                                                                                                       \
+    if ((src_).dtype == TDK_F32 && (dst_).dtype == TDK_F32) { using TI = float; using TO = float; const TI* src = reinterpret_cast<const TI*>((src_).p); TO* dst = reinterpret_cast<TO*>((dst_).p); __VA_ARGS__; } \
+    else if ((src_).dtype == TDK_F16 && (dst_).dtype == TDK_F32) { using TI = __half; using TO = float; const TI* src = reinterpret_cast<const TI*>((src_).p); TO* dst = reinterpret_cast<TO*>((dst_).p); __VA_ARGS__; } \
+    else if ((src_).dtype == TDK_F32 && (dst_).dtype == TDK_F16) { using TI = float; using TO = __half; const TI* src = reinterpret_cast<const TI*>((src_).p); TO* dst = reinterpret_cast<TO*>((dst_).p); __VA_ARGS__; } \
+    else { using TI = __half; using TO = __half; const TI* src = reinterpret_cast<const TI*>((src_).p); TO* dst = reinterpret_cast<TO*>((dst_).p); __VA_ARGS__; } \
+  } while (0)
+
+int stage_count(int color_smoothing_passes, int green_eq_local, int green_eq_global) {
   const int passes = color_smoothing_passes > 0 ? color_smoothing_passes : 0;
-  const int stages = (passes + FMAXP - 1) / FMAXP + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);  // <= FMAXP passes per launch
+  return (passes + FMAXP - 1) / FMAXP + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);  // <= FMAXP passes per launch
+}
+// fp32 images between the stages: one for fp32 callers (the other side of the ping-pong is the caller's output), up to two for
+// binary16 callers (every intermediate stays fp32: the result is the fp32 result rounded ONCE)
+int scratch_images(int stages, int dtype) { return dtype == TDK_F16 ? (stages >= 3 ? 2 : stages >= 2 ? 1 : 0) : (stages >= 2 ? 1 : 0); }
+}  // namespace
+
+TDK_EXPORT size_t tdk_postprocess_workspace_bytes_ex(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global, int dtype) {
+  if (width <= 0 || height <= 0) return 0;
+  const int stages = stage_count(color_smoothing_passes, green_eq_local, green_eq_global);
   size_t bytes = 256 + GEQ_BLOCKS * sizeof(float2);  // ratio + partial sums
-  if (stages >= 2) bytes += tdk_align_up((size_t)width * height * 3 * sizeof(float), 256);
+  bytes += (size_t)scratch_images(stages, dtype) * tdk_align_up((size_t)width * height * 3 * sizeof(float), 256);
   return tdk_align_up(bytes, 256);
 }
 
-TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* workspace, int width, int height, uint32_t pattern,
-                               int color_smoothing_passes, int green_eq_local, int green_eq_global, float green_eq_threshold,
-                               tdk_stream_t stream) {
+TDK_EXPORT size_t tdk_postprocess_workspace_bytes(int width, int height, int color_smoothing_passes, int green_eq_local, int green_eq_global) {
+  return tdk_postprocess_workspace_bytes_ex(width, height, color_smoothing_passes, green_eq_local, green_eq_global, TDK_F32);
+}
+
+TDK_EXPORT int tdk_postprocess_ex(const void* rgb_in, void* rgb_out, void* workspace, int width, int height, uint32_t pattern, int color_smoothing_passes,
+                                  int green_eq_local, int green_eq_global, float green_eq_threshold, int dtype, tdk_stream_t stream) {
   TDK_REQUIRE(rgb_in && rgb_out && workspace, "tdk_postprocess: null pointer");
   TDK_REQUIRE(rgb_in != rgb_out, "tdk_postprocess: in and out must not alias");
   TDK_REQUIRE(width > 0 && height > 0, "tdk_postprocess: invalid size %dx%d", width, height);
+  TDK_REQUIRE(dtype == TDK_F32 || dtype == TDK_F16, "unsupported dtype tag %d", dtype);
   hipStream_t s = tdk_stream(stream);
   const int passes = color_smoothing_passes > 0 ? color_smoothing_passes : 0;
-  const int stages = (passes + FMAXP - 1) / FMAXP + (green_eq_local ? 1 : 0) + (green_eq_global ? 1 : 0);
-  const size_t img_bytes = (size_t)width * height * 3 * sizeof(float);
+  const int stages = stage_count(color_smoothing_passes, green_eq_local, green_eq_global);
+  const size_t elem = dtype == TDK_F16 ? 2 : 4;
   if (stages == 0) {
-    TDK_HIP_CALL(hipMemcpyAsync(rgb_out, rgb_in, img_bytes, hipMemcpyDeviceToDevice, s), "tdk_postprocess(copy)");
+    TDK_HIP_CALL(hipMemcpyAsync(rgb_out, rgb_in, (size_t)width * height * 3 * elem, hipMemcpyDeviceToDevice, s), "tdk_postprocess(copy)");
     return TDK_OK;
   }
   char* ws = reinterpret_cast<char*>(workspace);
   float* ratio = reinterpret_cast<float*>(ws);
   float2* partial = reinterpret_cast<float2*>(ws + 256);
-  float* scratch = reinterpret_cast<float*>(ws + 256 + GEQ_BLOCKS * sizeof(float2));
+  char* scratch0 = ws + 256 + GEQ_BLOCKS * sizeof(float2);
+  char* scratch1 = scratch0 + tdk_align_up((size_t)width * height * 3 * sizeof(float), 256);
   const int64_t npix = (int64_t)width * height;
-  const int vec_ok = (width % 4 == 0) && tdk_aligned(rgb_out, 16) && tdk_aligned(scratch, 16);
-  const bool vec_io = vec_ok && tdk_aligned(rgb_in, 16);  // kernels that also READ with 16-B accesses
+  const bool w4 = width % 4 == 0;
 
-  const float* src = rgb_in;
+  const Img user_out{rgb_out, dtype};
+  auto dst_of = [&](int i) -> Img {
+    if (i == stages - 1) return user_out;
+    if (dtype == TDK_F32) return ((stages - 1 - i) % 2 == 0) ? user_out : Img{scratch0, TDK_F32};  // ping-pong through the caller's output
+    return Img{(i % 2 == 0) ? scratch0 : scratch1, TDK_F32};
+  };
+  Img src_img{const_cast<void*>(rgb_in), dtype};
   int stage = 0;
-  auto dst_of = [&](int i) { return ((stages - 1 - i) % 2 == 0) ? rgb_out : scratch; };
 
   for (int left = passes; left > 0; left -= FMAXP, stage++) {
-    float* dst = dst_of(stage);
+    const Img dst_img = dst_of(stage);
     const int n = left < FMAXP ? left : FMAXP;
-    TDK_LAUNCH("tdk_postprocess(color_smoothing)", smoothing_fused_kernel, dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(SNT), 0, s, src, dst, width,
-               height, (int)(vec_ok && tdk_aligned(src, 16)), (int)(vec_ok && tdk_aligned(dst, 16)), n);
-    src = dst;
+    PP_TYPES(src_img, dst_img,
+             TDK_LAUNCH("tdk_postprocess(color_smoothing)", (smoothing_fused_kernel<TI, TO>), dim3(tdk_div_up(width, STW), tdk_div_up(height, STH)), dim3(SNT), 0, s,
+                        src, dst, width, height, (int)(w4 && src_img.aligned4()), (int)(w4 && dst_img.aligned4()), n));
+    src_img = dst_img;
   }
   if (green_eq_global) {
-    float* dst = dst_of(stage++);
+    const Img dst_img = dst_of(stage++);
     const int nb = (int)(tdk_div_up64(npix, 256) < GEQ_BLOCKS ? tdk_div_up64(npix, 256) : GEQ_BLOCKS);
-    TDK_LAUNCH("tdk_postprocess(green_sums)", green_sums_kernel, dim3(nb), dim3(256), 0, s, src, width, height, pattern, partial);
+    const bool vec_io = w4 && src_img.aligned4() && dst_img.aligned4();
+    PP_TYPES(src_img, dst_img, {
+      (void)dst;
+      TDK_LAUNCH("tdk_postprocess(green_sums)", green_sums_kernel<TI>, dim3(nb), dim3(256), 0, s, src, width, height, pattern, partial);
+    });
     TDK_LAUNCH("tdk_postprocess(green_ratio)", green_ratio_kernel, dim3(1), dim3(256), 0, s, partial, nb, ratio);
-    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel<4>, row_grid(width / 4, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
-    else TDK_LAUNCH("tdk_postprocess(green_apply)", green_apply_kernel<1>, row_grid(width, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
-    src = dst;
+    PP_TYPES(src_img, dst_img, {
+      if (vec_io) TDK_LAUNCH("tdk_postprocess(green_apply)", (green_apply_kernel<4, TI, TO>), row_grid(width / 4, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
+      else TDK_LAUNCH("tdk_postprocess(green_apply)", (green_apply_kernel<1, TI, TO>), row_grid(width, height), dim3(256), 0, s, src, dst, width, height, pattern, ratio);
+    });
+    src_img = dst_img;
   }
   if (green_eq_local) {
-    float* dst = dst_of(stage++);
+    const Img dst_img = dst_of(stage++);
     // postprocess.cu:383: threshold / 100. is evaluated in double and narrowed
     const float thr = (float)((double)green_eq_threshold / 100.0);
     const dim3 lgrid(tdk_div_up(width, GLW), tdk_div_up(height, GLH));
-    if (vec_io) TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<4>, lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
-    else TDK_LAUNCH("tdk_postprocess(green_local)", green_local_kernel<1>, lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
-    src = dst;
+    const bool vec_io = w4 && src_img.aligned4() && dst_img.aligned4();
+    PP_TYPES(src_img, dst_img, {
+      if (vec_io) TDK_LAUNCH("tdk_postprocess(green_local)", (green_local_kernel<4, TI, TO>), lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
+      else TDK_LAUNCH("tdk_postprocess(green_local)", (green_local_kernel<1, TI, TO>), lgrid, dim3(256), 0, s, src, dst, width, height, pattern, thr);
+    });
+    src_img = dst_img;
   }
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_postprocess(const float* rgb_in, float* rgb_out, void* workspace, int width, int height, uint32_t pattern,
+                               int color_smoothing_passes, int green_eq_local, int green_eq_global, float green_eq_threshold,
+                               tdk_stream_t stream) {
+  return tdk_postprocess_ex(rgb_in, rgb_out, workspace, width, height, pattern, color_smoothing_passes, green_eq_local, green_eq_global, green_eq_threshold,
+                            TDK_F32, stream);
+}
+
+TDK_EXPORT int tdk_apply_white_balance_ex(const void* bayer_in, void* bayer_out, const float* gains, int width, int height, uint32_t pattern, int dtype,
+                                          tdk_stream_t stream) {
+  TDK_REQUIRE(bayer_in && bayer_out && gains, "tdk_apply_white_balance: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0, "tdk_apply_white_balance: invalid size %dx%d", width, height);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_apply_white_balance", white_balance_kernel<T>, row_grid(width, height), dim3(256), 0, tdk_stream(stream),
+                                          reinterpret_cast<const T*>(bayer_in), reinterpret_cast<T*>(bayer_out), gains, width, height, pattern));
   return TDK_OK;
 }
 
 TDK_EXPORT int tdk_apply_white_balance(const float* bayer_in, float* bayer_out, const float* gains, int width, int height, uint32_t pattern,
                                        tdk_stream_t stream) {
-  TDK_REQUIRE(bayer_in && bayer_out && gains, "tdk_apply_white_balance: null pointer");
-  TDK_REQUIRE(width > 0 && height > 0, "tdk_apply_white_balance: invalid size %dx%d", width, height);
-  const int64_t npix = (int64_t)width * height;
-  TDK_LAUNCH("tdk_apply_white_balance", white_balance_kernel, row_grid(width, height), dim3(256), 0, tdk_stream(stream), bayer_in, bayer_out, gains, width,
-                     height, pattern);
-  return TDK_OK;
+  return tdk_apply_white_balance_ex(bayer_in, bayer_out, gains, width, height, pattern, TDK_F32, stream);
 }

@@ -18,7 +18,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void wb_collect_kernel(const float* __restrict__ bayer, int width, int sw, int sh, uint32_t pattern, int step,
+template <typename T>
+__global__ __launch_bounds__(256) void wb_collect_kernel(const T* __restrict__ bayer, int width, int sw, int sh, uint32_t pattern, int step,
                                                          float* __restrict__ chroma, float* __restrict__ intensity, uint8_t* __restrict__ mask) {
   for (int i = blockIdx.y; i < sh; i += gridDim.y)
     for (int j = blockIdx.x * 256 + threadIdx.x; j < sw; j += gridDim.x * 256) {
@@ -26,8 +27,8 @@ __global__ __launch_bounds__(256) void wb_collect_kernel(const float* __restrict
       float cr = 0.0f, cg = 0.0f, s = 0.0f;
       uint8_t ok = 0;
       if (j + 1 < sw && i + 1 < sh) {
-        const float* q = bayer + (size_t)(i * step) * width + j * step;
-        const float p00 = q[0], p01 = q[1], p10 = q[width], p11 = q[width + 1];
+        const size_t q = (size_t)(i * step) * width + j * step;
+        const float p00 = ld<T>(bayer, q), p01 = ld<T>(bayer, q + 1), p10 = ld<T>(bayer, q + width), p11 = ld<T>(bayer, q + width + 1);
         float r, g, b;
         switch (pattern) {
           case TDK_PATTERN_RGGB: r = p00; g = (p01 + p10) * 0.5f; b = p11; break;
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void wb_collect_kernel(const float* __restrict
 
 }  // namespace
 
-TDK_EXPORT int tdk_wb_collect_samples(const float* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
-                                      float* intensity, uint8_t* mask, tdk_stream_t stream) {
+TDK_EXPORT int tdk_wb_collect_samples_ex(const void* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
+                                         float* intensity, uint8_t* mask, int dtype, tdk_stream_t stream) {
   TDK_REQUIRE(bayer && chroma && intensity && mask, "tdk_wb_collect_samples: null pointer");
   TDK_REQUIRE(stride >= 2, "tdk_wb_collect_samples: stride must be >= 2 (a sample is a 2x2 CFA quad), got %d", stride);
   TDK_REQUIRE(width >= stride && height >= stride, "tdk_wb_collect_samples: image %dx%d smaller than the stride %d", width, height, stride);
@@ -58,7 +59,12 @@ TDK_EXPORT int tdk_wb_collect_samples(const float* bayer, int width, int height,
   TDK_REQUIRE(tdk_aligned(chroma, 8), "tdk_wb_collect_samples: chroma must be 8-byte aligned");
   const int sw = width / stride, sh = height / stride;
   const dim3 grid((unsigned)tdk_div_up(sw, 256), (unsigned)(sh < 32768 ? sh : 32768));
-  TDK_LAUNCH("tdk_wb_collect_samples", wb_collect_kernel, grid, dim3(256), 0, tdk_stream(stream), bayer, width, sw, sh, pattern,
-             literal_positions ? 2 : stride, chroma, intensity, mask);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_wb_collect_samples", wb_collect_kernel<T>, grid, dim3(256), 0, tdk_stream(stream), reinterpret_cast<const T*>(bayer),
+                                          width, sw, sh, pattern, literal_positions ? 2 : stride, chroma, intensity, mask));
   return TDK_OK;
+}
+
+TDK_EXPORT int tdk_wb_collect_samples(const float* bayer, int width, int height, uint32_t pattern, int stride, int literal_positions, float* chroma,
+                                      float* intensity, uint8_t* mask, tdk_stream_t stream) {
+  return tdk_wb_collect_samples_ex(bayer, width, height, pattern, stride, literal_positions, chroma, intensity, mask, TDK_F32, stream);
 }

@@ -80,6 +80,12 @@ SIGNATURES = {
   'tdk_bilateral_rgb': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
   'tdk_laplacian_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
   'tdk_laplacian': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+  'tdk_postprocess_workspace_bytes_ex': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+  'tdk_postprocess_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+  'tdk_apply_white_balance_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, c_void_p]),
+  'tdk_wb_collect_samples_ex': (c_int, [c_void_p, c_int, c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+  'tdk_color_op_ex': (c_int, [c_void_p, c_void_p, c_int64, c_int, C.POINTER(c_float), c_void_p, c_int, c_void_p]),
+  'tdk_laplacian_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'tdk_jpeg_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
   'tdk_jpeg_encode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(c_size_t), c_void_p]),
   'tdk_jpeg_retrieve': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -303,7 +303,7 @@ class PostProcess(_Workspace):
 
   def process(self, input: torch.Tensor) -> torch.Tensor:
     _require(input.is_cuda, 'Input tensor must be on CUDA device')
-    _require(input.dtype == torch.float32, 'Input tensor must be float32')
+    tag = _dtype_tag(input)  # float32, or float16 storage (extension): the fp32 result rounded once
     _require(input.dim() == 3, 'Input tensor must be 3D (H, W, 3)')
     _require(input.size(2) == 3, 'Input must have 3 channels (RGB)')
     _require(input.size(0) == self._height and input.size(1) == self._width,
@@ -311,23 +311,24 @@ class PostProcess(_Workspace):
     x = input.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-      nbytes = lib.tdk_postprocess_workspace_bytes(self._width, self._height, self.color_smoothing_passes, int(self.green_eq_local),
-                                                   int(self.green_eq_global))
+      nbytes = lib.tdk_postprocess_workspace_bytes_ex(self._width, self._height, self.color_smoothing_passes, int(self.green_eq_local),
+                                                      int(self.green_eq_global), tag)
       ws = _workspace(nbytes, x.device)
-      check(lib.tdk_postprocess(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._pattern, self.color_smoothing_passes,
-                                int(self.green_eq_local), int(self.green_eq_global), self.green_eq_threshold, _stream()))
+      check(lib.tdk_postprocess_ex(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._pattern, self.color_smoothing_passes,
+                                   int(self.green_eq_local), int(self.green_eq_global), self.green_eq_threshold, tag, _stream()))
     return out
 
 
 # ------------------------------------------------------------------ white balance (csrc/white_balance.cu)
 def apply_white_balance(bayer_image: torch.Tensor, gains: torch.Tensor, pattern) -> torch.Tensor:
-  _require(bayer_image.is_cuda and bayer_image.dtype == torch.float32 and bayer_image.dim() == 2, 'bayer_image must be a float32 CUDA (H, W) tensor')
+  _require(bayer_image.is_cuda and bayer_image.dtype in (torch.float32, torch.float16) and bayer_image.dim() == 2,
+           'bayer_image must be a float32 CUDA (H, W) tensor')  # float16 storage: extension
   x = bayer_image.contiguous()
   g = gains.to(device=x.device, dtype=torch.float32).contiguous()
   _require(g.numel() == 3, 'gains must have 3 elements')
   out = torch.empty_like(x)
   with torch.cuda.device(x.device):
-    check(lib.tdk_apply_white_balance(_ptr(x), _ptr(out), _ptr(g), x.size(1), x.size(0), _pattern(pattern), _stream()))
+    check(lib.tdk_apply_white_balance_ex(_ptr(x), _ptr(out), _ptr(g), x.size(1), x.size(0), _pattern(pattern), _dtype_tag(x), _stream()))
   return out
 
 
@@ -360,11 +361,11 @@ def estimate_white_balance(bayer_images: Sequence[torch.Tensor], pattern, quanti
   mask = torch.empty(n, dtype=torch.bool, device=dev)
   with torch.cuda.device(dev):
     for i, img in enumerate(bayer_images):
-      _require(img.is_cuda and img.dim() == 2 and img.dtype == torch.float32, 'bayer images must be float32 CUDA (H, W) tensors')
+      _require(img.is_cuda and img.dim() == 2 and img.dtype in (torch.float32, torch.float16), 'bayer images must be float32 CUDA (H, W) tensors')
       _require(tuple(img.shape) == (h, w) and img.device == dev, 'all bayer images must have the same size and device')
       x = img.contiguous()
-      check(lib.tdk_wb_collect_samples(_ptr(x), w, h, pat, stride, int(literal_positions), _ptr(chroma[i * per:]), _ptr(inten[i * per:]),
-                                       _ptr(mask[i * per:]), _stream()))
+      check(lib.tdk_wb_collect_samples_ex(_ptr(x), w, h, pat, stride, int(literal_positions), _ptr(chroma[i * per:]), _ptr(inten[i * per:]),
+                                          _ptr(mask[i * per:]), _dtype_tag(x), _stream()))
   chroma_all, inten_all = chroma[mask], inten[mask]
   if chroma_all.size(0) == 0:
     return torch.tensor([1.0, 1.0, 1.0], device=dev)
@@ -381,14 +382,14 @@ _COLOR_OPS = {'rgb_to_xyz': 0, 'xyz_to_lab': 1, 'lab_to_xyz': 2, 'xyz_to_rgb': 3
 
 
 def _color_op(name: str, input: torch.Tensor, params=(0.0, 0.0, 0.0), matrix: torch.Tensor | None = None) -> torch.Tensor:
-  _require(input.dtype == torch.float32, 'Input must be float32')
+  _require(input.dtype in (torch.float32, torch.float16), 'Input must be float32')  # float16 storage: extension (fp32 arithmetic, rounded once)
   _require(input.dim() == 3 and input.size(2) == 3, 'Input must be (H, W, 3)')
   _require(input.is_cuda, 'Input must be on CUDA device')
   _require(input.is_contiguous(), 'Input tensor must be contiguous')
   out = torch.empty_like(input)
   prm = (C.c_float * 3)(*[float(p) for p in params])
   with torch.cuda.device(input.device):
-    check(lib.tdk_color_op(_ptr(input), _ptr(out), input.size(0) * input.size(1), _COLOR_OPS[name], prm, _ptr(matrix), _stream()))
+    check(lib.tdk_color_op_ex(_ptr(input), _ptr(out), input.size(0) * input.size(1), _COLOR_OPS[name], prm, _ptr(matrix), _dtype_tag(input), _stream()))
   return out
 
 
@@ -867,7 +868,7 @@ class Laplacian(_Workspace):
     self.clarity = float(clarity)
 
   def process(self, input: torch.Tensor) -> torch.Tensor:
-    _require(input.dtype == torch.float32, 'Input tensor must be float32')
+    tag = _dtype_tag(input)  # float16 storage (extension) carries the same values: the reference's result is binary16 stored as float32
     _require(input.dim() == 2, 'Input tensor must be 2D')
     _require(input.size(0) == self._height and input.size(1) == self._width, 'Input tensor dimensions must match workspace dimensions')
     _require(input.is_cuda, 'Input tensor must be on CUDA device')
@@ -875,8 +876,8 @@ class Laplacian(_Workspace):
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
       ws = self._workspace(lib.tdk_laplacian_workspace_bytes(self._width, self._height, self._num_gamma), x.device)
-      check(lib.tdk_laplacian(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._num_gamma, self.sigma, self.shadows,
-                              self.highlights, self.clarity, _stream()))
+      check(lib.tdk_laplacian_ex(_ptr(x), _ptr(out), _ptr(ws), self._width, self._height, self._num_gamma, self.sigma, self.shadows,
+                                 self.highlights, self.clarity, tag, _stream()))
     return out
 
 
