@@ -82,6 +82,14 @@ def main():
         'aces_tonemap': (lambda: td.aces_tonemap(rgb, params), n * (3 * s + 3)),
         'rgb_to_lab (f32)': (lambda: td.rgb_to_lab(rgb32), n * 24),
     }
+    if a.storage == 'f16':  # the ops that accept binary16 storage since round 5 (fp32 arithmetic, one rounding at the store)
+        ops['PostProcess(3 smoothing + local eq) (f16 storage)'] = (lambda: post.process(rgb), n * 12)
+        ops['apply_white_balance (f16 storage)'] = (lambda: td.apply_white_balance(bayer.squeeze(-1), gains, td.BayerPattern.RGGB), n * 4)
+        ops['Laplacian.process (f16 storage)'] = (lambda: lap.process(lum), n * 4)
+        ops['rgb_to_lab (f16 storage)'] = (lambda: td.rgb_to_lab(rgb), n * 12)
+    u8 = td.reinhard_tonemap(rgb, metrics, params)
+    coder = td.Jpeg()
+    ops['Jpeg.encode (4:2:2, q94, incl. the copy of the stream to the host)'] = (lambda: coder.encode(u8), n * 3)
     ops['decode12 -> f32'] = (lambda: td.decode12_float(packed, ids_format=False), n * 1.5 + n * 4)
     ops['decode12 -> f16'] = (lambda: td.decode12_half(packed, ids_format=False), n * 1.5 + n * 2)
     ops['encode12 <- f32'] = (lambda: td.encode12_float(flat32, ids_format=False), n * 1.5 + n * 4)
