@@ -20,7 +20,8 @@
 //     the block's bit offset (atomicOr on the first and last dword it shares with its neighbours, plain stores in between).
 //  5. byte stuffing (0xFF -> 0xFF 0x00) as count / prefix sum / scatter over 4 KB chunks, straight into the final stream behind
 //     the headers the host has written there.
-// The coefficient planes are read three times (128 B per block: 50 MB for a 12 MP 4:2:2 frame) -- cheaper than keeping symbol lists.
+// The coefficients (128 B per block, groups of 64 blocks stored transposed so that a wave's accesses are contiguous segments: 50 MB for
+// a 12 MP 4:2:2 frame) are read three times -- cheaper than keeping symbol lists.
 // Progressive = SOF2 with one interleaved DC scan and one AC scan (1..63) per component; every block closes its own band
 // (EOBRUN = 1), so the block walks stay independent.
 #include "tdk_common.h"
@@ -633,12 +634,17 @@ template <int SUB> int launch_fdct(const uint8_t* img, uint32_t* coef, const Geo
   return TDK_OK;
 }
 
+// byte positions inside a scan are 32-bit on the device: the worst-case stream of the frame has to stay below 4 GB (about 1.2
+// gigapixels at 4:2:2; JPEG itself stops at 65 535 x 65 535)
+bool geo_supported(const Geo& g) { return (unsigned long long)g.nblocks * MAX_BLOCK_BYTES < 0xf0000000ull; }
+
 }  // namespace
 
 TDK_EXPORT size_t tdk_jpeg_workspace_bytes(int width, int height, int subsampling) {
   if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || subsampling < 0 || subsampling > 2) return 0;
   Geo g;
   make_geo(width, height, 3, subsampling, g);
+  if (!geo_supported(g)) return 0;
   return make_layout(g).total;
 }
 
@@ -652,6 +658,7 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
   hipStream_t st = tdk_stream(stream);
   Geo g;
   make_geo(width, height, input_format, subsampling, g);
+  TDK_REQUIRE(geo_supported(g), "tdk_jpeg_encode: image %dx%d too large (worst-case stream beyond 4 GB)", width, height);
   const Layout L = make_layout(g);
   uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
   uint32_t* coef = reinterpret_cast<uint32_t*>(ws + L.coef);

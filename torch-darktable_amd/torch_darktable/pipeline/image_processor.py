@@ -131,7 +131,9 @@ class ImageProcessor:
                                      f'with {self.padding} padding, got {bytes.numel()} bytes. ')
             payload = bytes[: bytes.numel() - self.padding] if self.padding > 0 else bytes
             rgb = self.rcd_workspace.process_packed(payload, self.white_balance, self.packed_format, self.storage_dtype)
-            return self.postprocess_workspace.process(rgb.float()).to(self.storage_dtype) if self.settings.postprocess else rgb
+            # (PostProcess takes the storage type as it is: fp32 between its stages, one rounding at its store -- the same bits as
+            # converting to float32 around it, without the two conversion passes)
+            return self.postprocess_workspace.process(rgb) if self.settings.postprocess else rgb
         return self.debayer(self.load_bytes(bytes)).to(self.storage_dtype)
 
     def debayer(self, bayer_image: torch.Tensor) -> torch.Tensor:
