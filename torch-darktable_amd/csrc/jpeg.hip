@@ -214,33 +214,47 @@ __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------ passes 2 - 4: the block walk
 enum { HIST = 0, LEN = 1, WRITE = 2 };
 
+// Bit sink of one block.  The dwords go either into the workgroup's LDS staging buffer (the usual case: LDS atomics on the dword a
+// block shares with its neighbour, plain LDS stores in between) or, for a workgroup whose segment does not fit it, straight into
+// the global stream (global atomicOr on the shared dwords: two per block, the price the staging buffer avoids -- 786 K atomics per
+// 12 MP frame made the pass 37 us instead of 22, profiles/r05/experiments/jpeg_write_atomics.txt).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct BitWriter {
-  uint32_t* buf;       // big-endian dwords of the unstuffed scan
+  uint32_t* gbuf;      // big-endian dwords of the unstuffed scan (global path)
+  lds_u32* lbuf;       // the workgroup's staging buffer (LDS path), dword 0 = the dword that holds the workgroup's first bit
+  bool to_lds;
   uint64_t acc;
   int n;               // valid low bits of acc
   size_t word;
   bool shared;         // the next dword to flush is shared with the previous block
-  __device__ __forceinline__ void start(uint32_t* b, uint64_t bitpos) {
-    buf = b;
+  __device__ __forceinline__ void start(uint64_t bitpos) {
     word = (size_t)(bitpos >> 5);
     n = (int)(bitpos & 31);
     acc = 0;
     shared = n != 0;
   }
+  __device__ __forceinline__ void flush(uint32_t wv, bool atomic) {
+    if (to_lds) {
+      if (atomic) __hip_atomic_fetch_or(lbuf + word, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else lbuf[word] = wv;
+    } else {
+      if (atomic) atomicOr(gbuf + word, wv);
+      else gbuf[word] = wv;
+    }
+  }
   __device__ __forceinline__ void put(uint32_t code, int len) {
     acc = (acc << len) | code;
     n += len;
     if (n >= 32) {
-      const uint32_t wv = (uint32_t)(acc >> (n - 32));
-      if (shared) { atomicOr(buf + word, wv); shared = false; }
-      else buf[word] = wv;
+      flush((uint32_t)(acc >> (n - 32)), shared);
+      shared = false;
       word++;
       n -= 32;
       acc &= (1ull << n) - 1ull;
     }
   }
   __device__ __forceinline__ void finish() {
-    if (n > 0) atomicOr(buf + word, (uint32_t)(acc << (32 - n)));
+    if (n > 0) flush((uint32_t)(acc << (32 - n)), true);
   }
 };
 
@@ -280,6 +294,8 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
   constexpr int COPIES = MODE == HIST ? 8 : 1, CSTRIDE = 1025;
   __shared__ uint32_t lt[MODE == HIST ? COPIES * CSTRIDE : 1024];
   __shared__ uint32_t wsum[4];
+  constexpr int LCAP = 4096;                         // dwords of the WRITE pass's staging buffer (a 12 MP frame at quality 94: ~260 per workgroup)
+  __shared__ uint32_t seg[MODE == WRITE ? LCAP : 1];
   if (MODE == HIST) for (int i = threadIdx.x; i < COPIES * CSTRIDE; i += 256) lt[i] = 0u;
   else for (int i = threadIdx.x; i < 1024; i += 256) lt[i] = tabs[i];
   __syncthreads();
@@ -293,6 +309,8 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
   const bool live = s < sc.nscan;
   uint32_t nbits_total = 0;
   BitWriter bw;
+  size_t w0 = 0, nw = 0;       // WRITE: first dword of the workgroup's segment in the stream, dwords it touches
+  unsigned long long o0 = 0, o1 = 0;
   if (MODE == WRITE) {
     // exclusive prefix of this workgroup's block lengths
     const uint32_t mylen = live ? lens[s] : 0u;
@@ -303,10 +321,28 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
       if ((int)(threadIdx.x & 63) >= o) incl += up;
     }
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    o0 = wgoff[blockIdx.x];
+    o1 = wgoff[blockIdx.x + 1];
+    if (chunk == nchunks - 1) o1 = (o1 + 7) & ~7ull;   // the scan's last block pads the last byte with ones
+    w0 = (size_t)(o0 >> 5);
+    nw = (size_t)((o1 + 31) >> 5) - w0;
+    bw.to_lds = nw <= (size_t)LCAP;
+    bw.gbuf = raw;
+    bw.lbuf = (lds_u32*)seg;
+    if (bw.to_lds) {
+      for (size_t i = threadIdx.x; i < nw; i += 256) seg[i] = 0u;
+    } else {
+      // the segment is larger than the staging buffer (noise at quality 100): blocks write the stream directly.  The dwords only this
+      // workgroup touches are cleared here; the two it may share with its neighbours were cleared by jpeg_scan_kernel.
+      const size_t end = (o1 & 31) ? nw - 1 : nw;   // a last dword that ends on the boundary is this workgroup's alone
+      for (size_t i = 1 + threadIdx.x; i < end; i += 256) raw[w0 + i] = 0u;
+      __threadfence();
+    }
     __syncthreads();
     uint32_t before = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before += wsum[k];
-    bw.start(raw, wgoff[blockIdx.x] + before + incl - mylen);
+    const unsigned long long bitpos = o0 + before + incl - mylen;
+    bw.start(bw.to_lds ? bitpos - ((unsigned long long)w0 << 5) : bitpos);
   }
 
   if (live) {
@@ -367,6 +403,15 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
       }
       bw.finish();
     }
+    if (bw.to_lds) {  // the staged segment to the stream: coalesced stores, an atomic only where a neighbouring workgroup shares the dword
+      __syncthreads();
+      for (size_t i = threadIdx.x; i < nw; i += 256) {
+        const uint32_t v = seg[i];
+        const bool shared_dword = (i == 0 && (o0 & 31)) || (i == nw - 1 && (o1 & 31));
+        if (shared_dword) atomicOr(raw + w0 + i, v);
+        else raw[w0 + i] = v;
+      }
+    }
   }
   }  // chunks
   if (MODE == HIST) {
@@ -391,7 +436,8 @@ struct Scal {
 // what: 0 = block lengths -> total_bits / nbytes / nchunks, 1 = 0xFF counts -> total_ff / seg_len
 // what = 1 also closes the stream behind this segment with EOI (the markers of a following scan overwrite it)
 __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n_host,
-                                                          Scal* __restrict__ sc, int what, uint8_t* __restrict__ segment, unsigned long long room) {
+                                                          Scal* __restrict__ sc, int what, uint8_t* __restrict__ segment, unsigned long long room,
+                                                          uint32_t* __restrict__ clear) {
   __shared__ uint64_t wtot[16];
   __shared__ uint64_t carry_s;
   const uint32_t n = what == 0 ? n_host : sc->nchunks;
@@ -410,7 +456,10 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restr
     __syncthreads();
     uint64_t before = carry_s;
     for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before += wtot[k];
-    if (i < n) out[i] = before + incl - v;
+    if (i < n) {
+      out[i] = before + incl - v;
+      if (what == 0) clear[(before + incl - v) >> 5] = 0u;   // the dword two workgroups of the WRITE pass may share
+    }
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = before + incl;
     __syncthreads();
@@ -418,6 +467,7 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) {
     out[n] = carry_s;
     if (what == 0) {
+      clear[carry_s >> 5] = 0u;   // the dword of the padding bits
       sc->total_bits = carry_s;
       sc->overflow = 0u;
       sc->nbytes = (unsigned int)((carry_s + 7) >> 3);
@@ -430,11 +480,6 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(const uint32_t* __restr
       else sc->overflow = 1u;
     }
   }
-}
-
-__global__ __launch_bounds__(256) void jpeg_zero_kernel(uint32_t* __restrict__ raw, const Scal* __restrict__ sc) {
-  const size_t nwords = ((size_t)sc->nbytes + 3) / 4 + 1;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) raw[i] = 0u;
 }
 
 // byte k of the unstuffed scan: big-endian inside its dword
@@ -761,12 +806,11 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
     TDK_HIP_CALL(hipMemcpyAsync(tabs, packed.data(), 4096, hipMemcpyHostToDevice, st), "tdk_jpeg_encode: table copy");
 
     TDK_LAUNCH("tdk_jpeg(lengths)", (jpeg_code_kernel<LEN>), dim3(nwg), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
-    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, wgsum, wgoff, (uint32_t)nwg, scal, 0, out, 0ull);
-    TDK_LAUNCH("tdk_jpeg(zero)", jpeg_zero_kernel, dim3((unsigned)persistent), dim3(256), 0, st, raw, scal);
+    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, wgsum, wgoff, (uint32_t)nwg, scal, 0, out, 0ull, raw);
     TDK_LAUNCH("tdk_jpeg(write)", (jpeg_code_kernel<WRITE>), dim3(nwg), dim3(256), 0, st, coef, g, sc, hist, tabs, lens, wgsum, wgoff, raw);
     TDK_LAUNCH("tdk_jpeg(count ff)", (jpeg_stuff_kernel<false>), dim3((unsigned)persistent), dim3(256), 0, st, raw, scal, ffcnt, ffoff, out,
                (unsigned long long)pos, (unsigned long long)(L.stream_cap - 2), scal);
-    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, ffcnt, ffoff, 0u, scal, 1, out + pos, (unsigned long long)(L.stream_cap - pos));
+    TDK_LAUNCH("tdk_jpeg(scan)", jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, ffcnt, ffoff, 0u, scal, 1, out + pos, (unsigned long long)(L.stream_cap - pos), raw);
     TDK_LAUNCH("tdk_jpeg(stuff)", (jpeg_stuff_kernel<true>), dim3((unsigned)persistent), dim3(256), 0, st, raw, scal, ffcnt, ffoff, out,
                (unsigned long long)pos, (unsigned long long)(L.stream_cap - 2), scal);
   }
