@@ -89,7 +89,7 @@ def main():
         ops['rgb_to_lab (f16 storage)'] = (lambda: td.rgb_to_lab(rgb), n * 12)
     u8 = td.reinhard_tonemap(rgb, metrics, params)
     coder = td.Jpeg()
-    ops['Jpeg.encode (4:2:2, q94, incl. the copy of the stream to the host)'] = (lambda: coder.encode(u8), n * 3)
+    ops['Jpeg.encode (4:2:2, q94; device kernels, the call also synchronises and copies the stream to the host)'] = (lambda: coder.encode(u8), n * 3)
     ops['decode12 -> f32'] = (lambda: td.decode12_float(packed, ids_format=False), n * 1.5 + n * 4)
     ops['decode12 -> f16'] = (lambda: td.decode12_half(packed, ids_format=False), n * 1.5 + n * 2)
     ops['encode12 <- f32'] = (lambda: td.encode12_float(flat32, ids_format=False), n * 1.5 + n * 4)
