@@ -38,7 +38,7 @@ def decode(stream):
     return im
 
 
-@pytest.mark.parametrize('h,w', [(8, 8), (17, 9), (64, 96), (203, 331), (100, 2100), (520, 1030)])
+@pytest.mark.parametrize('h,w', [(1, 1), (3, 2), (8, 8), (17, 9), (64, 96), (203, 331), (100, 2100), (520, 1030)])
 @pytest.mark.parametrize('sub', [0, 1, 2])
 @pytest.mark.parametrize('progressive', [False, True])
 def test_stream_identical_to_oracle(td, oracle, dev, h, w, sub, progressive):

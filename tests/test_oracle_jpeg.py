@@ -125,7 +125,7 @@ def test_optimal_tables_are_valid_prefix_codes(oracle):
 def test_extreme_images(oracle):
     """Constant, saturated and maximum-entropy images at the quality extremes: still valid streams."""
     rng = np.random.default_rng(11)
-    for img in (np.zeros((17, 9, 3), np.uint8), np.full((8, 8, 3), 255, np.uint8), rng.integers(0, 256, (40, 56, 3), dtype=np.uint8),
+    for img in (np.full((1, 1, 3), 77, np.uint8), rng.integers(0, 256, (3, 2, 3), dtype=np.uint8), np.zeros((17, 9, 3), np.uint8), np.full((8, 8, 3), 255, np.uint8), rng.integers(0, 256, (40, 56, 3), dtype=np.uint8),
                 (rng.integers(0, 2, (33, 47, 3)) * 255).astype(np.uint8)):
         for quality in (1, 100):
             for sub in (0, 1, 2):
