@@ -756,6 +756,12 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
   keep.reserve(plan.size() * 2 + 2);
   std::vector<std::vector<uint32_t>> keep_tabs;
   keep_tabs.reserve(plan.size());
+  // an early return (a failed launch or copy) must not free those sources under a copy that is still in flight
+  struct DrainOnExit {
+    hipStream_t s;
+    bool armed;
+    ~DrainOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+  } drain{st, true};
   size_t pos = 0;
   Bytes pending = hd;  // bytes to put in front of the next scan's entropy-coded segment
   const int persistent = tdk_device_cus() * 4;
@@ -819,6 +825,7 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
   TDK_REQUIRE(!hs.overflow, "tdk_jpeg_encode: stream larger than the workspace");
   pos += (size_t)hs.seg_len;
   *length = pos + 2;  // EOI is already there (jpeg_scan_kernel)
+  drain.armed = false;  // the stream was synchronised two lines up
   return TDK_OK;
 }
 
