@@ -31,5 +31,7 @@ python3 profiles/op_bench.py --storage f16 > $OUT/op_bench_f16.json 2> $OUT/op_b
 python3 profiles/op_bench.py --storage f32 > $OUT/op_bench_f32.json 2> $OUT/op_bench_f32.err || echo "op bench f32 failed"
 python3 profiles/op_bench.py --storage f16 --width 8192 --height 6144 --only "PPG|Wiener.process C=3" > $OUT/op_bench_50mp_f16.json 2> $OUT/op_bench_50mp_f16.err || echo "op bench 50 MP failed"
 python3 profiles/jpeg_bench.py --pillow > $OUT/jpeg_bench.txt 2>&1 || echo "jpeg bench failed"
+# rocprofv3 kernel table of the same encodes (its averages against the event-timer figures of jpeg_bench.txt)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_jpeg -o jpeg -- python3 profiles/jpeg_bench.py --iters 10 > $OUT/jpeg_under_rocprof.txt 2>&1 || echo "jpeg rocprof failed"
 python3 profiles/laplacian_kernels.py > $OUT/laplacian_kernels.txt 2>&1 || echo "laplacian kernels failed"
 echo capture done

@@ -17,13 +17,15 @@ tag = sys.argv[1]
 src, dst = Path('gpurun_out') / tag, Path('profiles') / tag
 dst.mkdir(exist_ok=True)
 for name in ['bench_isp_plain.json', 'bench_rcd_plain.json', 'bench_ppg_wiener50_plain.json', 'bench_isp_streams1_plain.json', 'bench_isp_streams2_plain.json', 'bench_isp_under_rocprof.json', 'op_bench_f16.json', 'op_bench_f32.json', 'op_bench_50mp_f16.json',
-             'laplacian_kernels.txt', 'traffic.json', 'bench_isp_repeats.txt']:
+             'laplacian_kernels.txt', 'traffic.json', 'bench_isp_repeats.txt', 'jpeg_bench.txt']:
     if (src / name).exists():
         shutil.copy(src / name, dst / name)
 shutil.copy(src / 'stats' / 'bench_kernel_stats.csv', dst / 'bench_isp_kernel_stats.csv')
 if (src / 'stats1' / 'bench_kernel_stats.csv').exists():
     shutil.copy(src / 'stats1' / 'bench_kernel_stats.csv', dst / 'bench_isp_streams1_kernel_stats.csv')
     shutil.copy(src / 'bench_isp_streams1_under_rocprof.json', dst / 'bench_isp_streams1_under_rocprof.json')
+if (src / 'stats_jpeg' / 'jpeg_kernel_stats.csv').exists():
+    shutil.copy(src / 'stats_jpeg' / 'jpeg_kernel_stats.csv', dst / 'jpeg_kernel_stats.csv')
 shutil.copy(src / 'traffic.json', Path('profiles') / 'traffic.json')
 for d in ['fetch', 'write', 'valu', 'sq2', 'sq3']:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
