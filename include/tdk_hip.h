@@ -171,6 +171,14 @@ int tdk_normalize(const void* in, void* out, int64_t count, const float* bounds,
  * once, then tdk_image_bounds_accumulate per image. */
 int tdk_image_bounds_init(float* bounds, tdk_stream_t stream);
 int tdk_image_bounds_accumulate(const void* rgb, int width, int height, int stride, float* bounds, int dtype, tdk_stream_t stream);
+/* The same without the init launch.  state: 4 device words that are {0xffffffff, 0, 0, 0} ("idle") before the first use and are left
+ * idle again by the call that finishes a list.  One call per image, stream-ordered; the calls of a list but the last pass
+ * bounds = NULL, the last one passes bounds (2 device floats) and total_tickets = the sum of tdk_image_bounds_tickets(width, height,
+ * stride) over ALL images of the list: the workgroup that draws that last ticket writes bounds and resets the state.  Results
+ * identical to _init + _accumulate (minimum and maximum are exact whatever the order). */
+int tdk_image_bounds_tickets(int width, int height, int stride);
+int tdk_image_bounds(const void* rgb, int width, int height, int stride, uint32_t* state, float* bounds, unsigned total_tickets, int dtype,
+                     tdk_stream_t stream);
 /* compute_image_metrics: color_adaption.cu:122-166.  acc: 8 floats of device scratch, zeroed by
  * _init; bounds: 2 device floats ({0,1} unless rescaling); _finish writes metrics[5] on device
  * (normalised by max(valid, 1)) without a host sync. */

@@ -16,7 +16,7 @@ def _declared_functions():
 
 def test_header_declares_the_expected_surface():
     names = _declared_functions()
-    assert len(names) == 65
+    assert len(names) == 67
     assert not any('select_path' in n for n in names)  # no process-global test hooks in the product ABI: paths are per-call flags
     for must in ('tdk_rcd', 'tdk_ppg', 'tdk_bilinear5x5', 'tdk_wiener', 'tdk_bilateral', 'tdk_laplacian', 'tdk_tonemap',
                  'tdk_color_op', 'tdk_decode12_f32', 'tdk_postprocess', 'tdk_image_metrics_finish'):

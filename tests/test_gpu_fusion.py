@@ -378,3 +378,32 @@ def test_frame_streams_batch_replays_as_one_graph(td, dev):
             torch.cuda.synchronize()
             for i, (o, e) in enumerate(zip(outs, want)):
                 assert torch.equal(o, e), (rep, i, (o != e).sum().item())
+
+
+def test_bounds_one_launch_equals_init_plus_accumulate(td, dev):
+    """compute_image_bounds through tdk_image_bounds (no init launch, a persistent state that is idle between calls, the last ticket of
+    the list writes the result) == the reference-shaped tdk_image_bounds_init + _accumulate calls: lists of 1 - 3 images, grids of 1 to
+    256 workgroups, both storage types, negative and large values, back-to-back calls on the same cached state."""
+    from torch_darktable._native import lib
+    from torch_darktable.torch_darktable_extension import _dtype_tag, _ptr, _stream, check
+
+    def two_call(images, stride):
+        b = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib.tdk_image_bounds_init(_ptr(b), _stream()))
+        for x in images:
+            check(lib.tdk_image_bounds_accumulate(_ptr(x), x.size(1), x.size(0), stride, _ptr(b), _dtype_tag(x), _stream()))
+        return b
+
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for rep in range(3):   # the cached state must come back idle every time
+        for shapes, stride in ((((8, 8),), 8), (((96, 128),), 2), (((512, 768), (100, 60)), 1), (((3072, 4096),), 8), (((40, 40), (64, 64), (700, 900)), 4)):
+            for dtype in (torch.float32, torch.float16):
+                images = [((torch.rand(h, w, 3, generator=g) - 0.3) * (1.0 + 7.0 * k)).to(dtype).to(dev) for k, (h, w) in enumerate(shapes)]
+                got = td.compute_image_bounds(images, stride)
+                want = two_call(images, stride)
+                assert torch.equal(got, want), (shapes, stride, dtype, got, want)
+    # a rejected list (second image on the wrong device / of the wrong type) leaves the state idle: the next call is right
+    good = (torch.rand(64, 64, 3, generator=g) * 2.0 - 0.5).to(dev)
+    with pytest.raises(RuntimeError):
+        td.compute_image_bounds([good, good.to(torch.int32)], 4)
+    assert torch.equal(td.compute_image_bounds([good], 4), two_call([good], 4))

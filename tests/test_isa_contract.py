@@ -64,6 +64,24 @@ def test_metrics_one_launch_handoff_instructions(tonemap_asm):
         assert any(l.startswith('s_waitcnt vmcnt(0)') for l in between) and any(l.startswith('s_barrier') for l in between), name
 
 
+def test_bounds_one_launch_handoff_instructions(tonemap_asm):
+    """tdk_image_bounds (bounds_ticket_kernel): the same fence-less hand-off as the metrics kernel.  Minimum and maximum are single
+    integer atomics on order-preserving keys (no compare-and-swap loop on cached data), they have completed (vmcnt(0)) before the
+    returning ticket atomic is issued, and the workgroup that draws the last ticket reads the two keys with agent-scope loads."""
+    ks = _kernels(tonemap_asm, r'bounds_ticket_kernelI')
+    assert len(ks) == 2, list(ks)
+    for name, body in ks.items():
+        ops = [l.split()[0] for l in body if l and not l.startswith((';', '.'))]
+        assert ops.count('global_atomic_umin') == 1 and ops.count('global_atomic_umax') == 1, name
+        assert not any(o.startswith('global_atomic_cmpswap') for o in ops), f'{name}: a compare-and-swap loop appeared'
+        ticket = [i for i, l in enumerate(body) if l.startswith('global_atomic_add ') and 'sc0' in l]
+        assert len(ticket) == 1, name
+        umax = next(i for i, l in enumerate(body) if l.startswith('global_atomic_umax'))
+        assert umax < ticket[0] and any(l.startswith('s_waitcnt vmcnt(0)') for l in body[umax:ticket[0]]), name
+        tail_loads = [l for l in body[ticket[0]:] if l.startswith('global_load_dword')]
+        assert len(tail_loads) == 2 and all(' sc1' in l for l in tail_loads), f'{name}: key loads without agent scope: {tail_loads}'
+
+
 def test_rcd_approximate_flavour_has_no_ieee_division_in_its_inner_blocks():
     asm = _asm('rcd')
     ks = _kernels(asm, r'(rcd_quadILi4E\w+Lb1E|rcd_streamI\w+Lb1E)')

@@ -73,6 +73,50 @@ __global__ __launch_bounds__(256) void bounds_kernel(const T* __restrict__ img, 
   }
 }
 
+// compute_image_bounds without the init launch: a persistent 4-word state {min key, max key, ticket, -} that is IDLE = {~0, 0, 0, 0}
+// between calls.  Keys are the order-preserving integer images of the floats, so a workgroup's contribution is ONE memory-side
+// global_atomic_umin / umax each (no CAS loop); every workgroup of every image of a list then draws a ticket, and the one that draws
+// the last ticket of the list (`total`, passed with the list's last launch) decodes the two keys into bounds[0..1] and puts the
+// state back to idle.  The hand-off is the metrics kernel's: the lane's two atomics have completed (s_waitcnt vmcnt(0)) before it
+// draws its agent-scope ticket, the last arriver reads the keys with agent-scope loads; launches of a list are stream-ordered.
+__device__ __forceinline__ uint32_t float_key(float f) { const uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void bounds_ticket_kernel(const T* __restrict__ img, int width, int height, int stride, int sw, int sh,
+                                                            uint32_t* __restrict__ state, float* __restrict__ finish_to, unsigned total) {
+  __shared__ float smin[4], smax[4];
+  const int64_t n = (int64_t)sw * sh;
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int sy = (int)(i / sw), sx = (int)(i - (int64_t)sy * sw);
+    const size_t p = ((size_t)(sy * stride) * width + (size_t)sx * stride) * 3;
+    const float r = ld(img, p), g = ld(img, p + 1), b = ld(img, p + 2);
+    lo = fminf(lo, fminf(fminf(r, g), b));
+    hi = fmaxf(hi, fmaxf(fmaxf(r, g), b));
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smin[wave] = lo; smax[wave] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_min(&state[0], float_key(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(&state[1], float_key(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both have reached memory before the ticket is drawn
+    const unsigned t = __hip_atomic_fetch_add(&state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (finish_to && t == total - 1u) {
+      const uint32_t kmin = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t kmax = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      finish_to[0] = key_float(kmin);
+      finish_to[1] = key_float(kmax);
+      state[0] = 0xffffffffu;  // idle again (the next list's first launch is stream-ordered behind this kernel)
+      state[1] = 0u;
+      state[2] = 0u;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ metrics
 __global__ void metrics_init_kernel(float* acc) {
   if (threadIdx.x < 8) acc[threadIdx.x] = 0.0f;
@@ -382,6 +426,23 @@ TDK_EXPORT int tdk_image_bounds_accumulate(const void* rgb, int width, int heigh
   const int grid = reduce_grid((int64_t)sw * sh);
   TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_bounds_accumulate", bounds_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream),
                                                   reinterpret_cast<const T*>(rgb), width, height, stride, sw, sh, bounds));
+  return TDK_OK;
+}
+
+TDK_EXPORT int tdk_image_bounds_tickets(int width, int height, int stride) {
+  if (width <= 0 || height <= 0 || stride <= 0) return 0;
+  return reduce_grid((int64_t)tdk_div_up(width, stride) * tdk_div_up(height, stride));
+}
+
+TDK_EXPORT int tdk_image_bounds(const void* rgb, int width, int height, int stride, uint32_t* state, float* bounds, unsigned total_tickets, int dtype,
+                                tdk_stream_t stream) {
+  TDK_REQUIRE(rgb && state, "tdk_image_bounds: null pointer");
+  TDK_REQUIRE(width > 0 && height > 0 && stride > 0, "tdk_image_bounds: invalid size/stride");
+  const int sw = tdk_div_up(width, stride), sh = tdk_div_up(height, stride);
+  const int grid = reduce_grid((int64_t)sw * sh);
+  TDK_REQUIRE(!bounds || total_tickets >= (unsigned)grid, "tdk_image_bounds: total_tickets %u smaller than this launch's %d", total_tickets, grid);
+  TDK_DISPATCH_DTYPE(dtype, T, TDK_LAUNCH("tdk_image_bounds", bounds_ticket_kernel<T>, dim3(grid), dim3(256), 0, tdk_stream(stream), reinterpret_cast<const T*>(rgb),
+                                          width, height, stride, sw, sh, state, bounds, total_tickets));
   return TDK_OK;
 }
 

@@ -54,6 +54,8 @@ SIGNATURES = {
   'tdk_normalize': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
   'tdk_image_bounds_init': (c_int, [c_void_p, c_void_p]),
   'tdk_image_bounds_accumulate': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+  'tdk_image_bounds_tickets': (c_int, [c_int, c_int, c_int]),
+  'tdk_image_bounds': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, C.c_uint, c_int, c_void_p]),
   'tdk_image_metrics_init': (c_int, [c_void_p, c_void_p]),
   'tdk_image_metrics_accumulate': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
   'tdk_image_metrics_finish': (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -503,17 +503,32 @@ def normalize_image(image: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
   return out
 
 
+_BOUNDS_STATE: dict = {}
+
+
 def compute_image_bounds(images: Sequence[torch.Tensor], stride: int = 8) -> torch.Tensor:
+  """One launch per image (tdk_image_bounds): minimum and maximum go through a persistent per-(device, stream) state of four words that is
+  idle between calls, the workgroup that draws the list's last ticket writes the result and resets it -- no init launch."""
   _require(len(images) > 0, 'images must be non-empty')
   dev = images[0].device
-  for img in images:
+  for img in images:  # every image is checked before the first launch: a rejected list leaves the cached state idle
     _check_rgb(img, allow_half=True)
+    _require(img.device == dev, f'image is on {img.device}, the first one on {dev}')
   bounds = torch.empty(2, dtype=torch.float32, device=dev)
+  key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
   with torch.cuda.device(dev):
-    check(lib.tdk_image_bounds_init(_ptr(bounds), _stream()))
-    for img in images:
-      x = img.contiguous()
-      check(lib.tdk_image_bounds_accumulate(_ptr(x), x.size(1), x.size(0), int(stride), _ptr(bounds), _dtype_tag(x), _stream()))
+    state = _BOUNDS_STATE.get(key)
+    if state is None:
+      state = _BOUNDS_STATE[key] = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)  # 0xffffffff, 0, 0, 0 (host copy: complete on return)
+    xs = [img.contiguous() for img in images]
+    total = sum(lib.tdk_image_bounds_tickets(x.size(1), x.size(0), int(stride)) for x in xs)
+    try:
+      for i, x in enumerate(xs):
+        last = i == len(xs) - 1
+        check(lib.tdk_image_bounds(_ptr(x), x.size(1), x.size(0), int(stride), _ptr(state), _ptr(bounds) if last else None, total, _dtype_tag(x), _stream()))
+    except Exception:
+      _BOUNDS_STATE.pop(key, None)  # a failed launch may have left tickets behind: start from a fresh state next time
+      raise
   return bounds
 
 
