@@ -143,6 +143,15 @@ template <bool HAS_CLARITY> __device__ __forceinline__ float curve(float x, floa
   const float ssigma = copysignf(k.sigma, c);
   const float shadhi = c > 0.0f ? k.shadows : k.highlights;
   const float lin = g + ssigma + shadhi * (c - ssigma);  // linear part
+#ifndef TDK_LAP_NO_SHORTCUT
+  // Every lane of the wave beyond 2 sigma of this gamma centre (neighbouring samples are: with sigma = 0.2 a third of the (sample, gamma)
+  // pairs of an image): the bezier branch below would be computed and discarded by the select -- skip it, the result is the same `lin`.
+  if (__builtin_amdgcn_ballot_w64(!(fabsf(c) > k.two_sigma)) == 0) {
+    float v = lin;
+    if constexpr (HAS_CLARITY) v += k.clarity * c * __builtin_amdgcn_exp2f(c * c * k.neg_inv_e);
+    return v;
+  }
+#endif
   // blend in via quadratic bezier
   const float d = 2.0f * ssigma;
   float q;
