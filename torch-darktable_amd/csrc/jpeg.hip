@@ -28,6 +28,8 @@
 
 #include <string.h>
 
+#include <type_traits>
+
 #include <vector>
 
 namespace {
@@ -99,18 +101,24 @@ template <int SUB> struct Tile {
   static constexpr int TPX = SUB == 0 ? 512 : SUB == 1 ? 1024 : 2048;
   static constexpr int NYB = TPX / 8;                              // Y blocks
   static constexpr int NCB = SUB == 0 ? TPX / 8 : SUB == 1 ? TPX / 16 : 0;  // blocks per chroma component
-  static constexpr int PY = NYB + 16, PC = NCB + 16;               // plane pitches (int16 entries per sample position)
-  static constexpr int LDS_BYTES = (64 * PY + 2 * 64 * (NCB ? PC : 0)) * 2;
+  // Y samples are bytes; chroma samples bytes too, except 4:2:2 where a site holds the SUM of its two pixels (<= 510): int16.  25 KB
+  // per workgroup at 4:2:2 (was 39 KB with int16 planes and wider pitches): six workgroups = 24 waves per CU instead of four.
+  using CT = typename std::conditional<SUB == 1, int16_t, uint8_t>::type;
+  static constexpr int PY = NYB + 4, PC = NCB + 4;                 // plane pitches (entries per sample position)
+  static constexpr int Y_BYTES = 64 * PY, C_BYTES = NCB ? 64 * PC * (int)sizeof(CT) : 0;
+  static constexpr int LDS_BYTES = Y_BYTES + 2 * C_BYTES;
   static_assert(NYB + 2 * NCB <= 256, "one thread per block");
+  static_assert(Y_BYTES % 4 == 0, "the chroma planes start aligned");
 };
 
 template <int SUB>
 __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ coef, Geo g, Quant qt) {
   using T = Tile<SUB>;
-  extern __shared__ int16_t jl[];
-  int16_t* sY = jl;
-  int16_t* sCb = jl + 64 * T::PY;
-  int16_t* sCr = sCb + 64 * T::PC;
+  using CT = typename T::CT;
+  extern __shared__ __align__(16) uint8_t jl[];
+  uint8_t* sY = jl;
+  CT* sCb = reinterpret_cast<CT*>(jl + T::Y_BYTES);
+  CT* sCr = sCb + 64 * T::PC;
   const int tile = blockIdx.x, my = blockIdx.y;
   const int x_tile = tile * T::TPX;
   const size_t plane = (size_t)g.w * g.h;
@@ -156,19 +164,19 @@ __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restric
     }
     const int lx = gx * 4;  // pixel column inside the tile
 #pragma unroll
-    for (int k = 0; k < 4; k++) sY[(r * 8 + ((lx + k) & 7)) * T::PY + ((lx + k) >> 3)] = (int16_t)yv[k];
+    for (int k = 0; k < 4; k++) sY[(r * 8 + ((lx + k) & 7)) * T::PY + ((lx + k) >> 3)] = (uint8_t)yv[k];
     if constexpr (SUB == 0) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        sCb[(r * 8 + ((lx + k) & 7)) * T::PC + ((lx + k) >> 3)] = (int16_t)cbv[k];
-        sCr[(r * 8 + ((lx + k) & 7)) * T::PC + ((lx + k) >> 3)] = (int16_t)crv[k];
+        sCb[(r * 8 + ((lx + k) & 7)) * T::PC + ((lx + k) >> 3)] = (CT)cbv[k];
+        sCr[(r * 8 + ((lx + k) & 7)) * T::PC + ((lx + k) >> 3)] = (CT)crv[k];
       }
     } else if constexpr (SUB == 1) {
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const int cx = lx / 2 + k;
-        sCb[(r * 8 + (cx & 7)) * T::PC + (cx >> 3)] = (int16_t)(cbv[2 * k] + cbv[2 * k + 1]);
-        sCr[(r * 8 + (cx & 7)) * T::PC + (cx >> 3)] = (int16_t)(crv[2 * k] + crv[2 * k + 1]);
+        sCb[(r * 8 + (cx & 7)) * T::PC + (cx >> 3)] = (CT)(cbv[2 * k] + cbv[2 * k + 1]);
+        sCr[(r * 8 + (cx & 7)) * T::PC + (cx >> 3)] = (CT)(crv[2 * k] + crv[2 * k + 1]);
       }
     }
   }
@@ -184,14 +192,18 @@ __global__ __launch_bounds__(256) void jpeg_fdct_kernel(const uint8_t* __restric
   const int per_tile = c == 0 ? T::NYB : T::NCB;
   const int bx = tile * per_tile + lb;
   if (bx >= g.nbx[c]) return;
-  const int16_t* src = c == 0 ? sY : c == 1 ? sCb : sCr;
-  const int pitch = c == 0 ? T::PY : T::PC;
   const bool halved = SUB == 1 && c != 0;
   float d[64];
+  if (c == 0) {
 #pragma unroll
-  for (int i = 0; i < 64; i++) {
-    const float s = (float)src[i * pitch + lb];
-    d[i] = halved ? s * 0.5f - 128.0f : s - 128.0f;
+    for (int i = 0; i < 64; i++) d[i] = (float)sY[i * T::PY + lb] - 128.0f;
+  } else {
+    const CT* src = c == 1 ? sCb : sCr;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      const float s = (float)src[i * T::PC + lb];
+      d[i] = halved ? s * 0.5f - 128.0f : s - 128.0f;
+    }
   }
 #pragma unroll
   for (int r = 0; r < 8; r++) fdct8(d[8 * r], d[8 * r + 1], d[8 * r + 2], d[8 * r + 3], d[8 * r + 4], d[8 * r + 5], d[8 * r + 6], d[8 * r + 7]);
