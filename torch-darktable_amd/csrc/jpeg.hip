@@ -63,6 +63,7 @@ struct Quant { float rq[2][64]; };   // 1 / (q * aan[v] * aan[u] * 8), natural o
 struct ScanDesc {
   int ns, comp0, ss, se;       // ns components starting with comp0 (ns > 1: all of them, interleaved)
   long long nscan;             // blocks the scan codes
+  int chunk;                   // scan positions per workgroup of the coding passes: 256, or 64 MCUs of an interleaved scan (256 at 4:2:2, 192 at 4:4:4)
 };
 
 // Coefficient store: block idx keeps its 64 zig-zag int16 as 32 dwords, dword j of block idx at ((idx / 64) * 32 + j) * 64 + idx % 64
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
   __shared__ uint32_t wsum[4];
   constexpr int LCAP = 4096;                         // dwords of the WRITE pass's staging buffer (a 12 MP frame at quality 94: ~260 per workgroup)
   __shared__ uint32_t seg[MODE == WRITE ? LCAP : 1];
+  __shared__ uint32_t pex[MODE == WRITE ? 256 : 1];
   if (MODE == HIST) for (int i = threadIdx.x; i < COPIES * CSTRIDE; i += 256) lt[i] = 0u;
   else for (int i = threadIdx.x; i < 1024; i += 256) lt[i] = tabs[i];
   __syncthreads();
@@ -315,18 +317,32 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
 
   // HIST runs a fixed grid over all chunks of 256 blocks (fewer workgroups = fewer same-address global atomics when the LDS
   // histograms are flushed); LEN and WRITE run one workgroup per chunk (their prefix sums are per chunk)
-  const long long nchunks = (sc.nscan + 255) / 256;
+  // Lane -> scan position inside the chunk.  An interleaved scan alternates the components (Y0 Y1 Cb Cr per MCU): taken in scan order
+  // the lanes of a wave would pick their coefficient dwords from three planes in runs of one or two blocks.  Instead the chunk's 64
+  // MCUs are taken component by component -- lanes 0 .. 64 hs - 1 the Y blocks, the next 64 Cb, the next 64 Cr -- so that a wave reads
+  // 64 CONSECUTIVE blocks of one plane (a full 256-byte row of the transposed store per load).  Lengths and offsets stay indexed by
+  // scan position; the WRITE pass's prefix sum runs over the chunk in scan order through LDS.
+  const int CH = sc.chunk;
+  int ls = threadIdx.x;      // local scan position
+  if (sc.ns > 1) {
+    const int bpm = g.hs0 + 2, ny = 64 * g.hs0, t = threadIdx.x;
+    if (t < ny) ls = (t / g.hs0) * bpm + (t % g.hs0);
+    else if (t < ny + 128) ls = ((t - ny) & 63) * bpm + g.hs0 + ((t - ny) >> 6);
+    else ls = CH;            // idle lane (4:4:4: 192 positions per chunk)
+  }
+  const long long nchunks = (sc.nscan + CH - 1) / CH;
   for (long long chunk = blockIdx.x; chunk < nchunks; chunk += (MODE == HIST ? (long long)gridDim.x : nchunks)) {
-  const long long s = chunk * 256 + threadIdx.x;
-  const bool live = s < sc.nscan;
+  const long long s = chunk * CH + ls;
+  const bool live = ls < CH && s < sc.nscan;
   uint32_t nbits_total = 0;
   BitWriter bw;
   size_t w0 = 0, nw = 0;       // WRITE: first dword of the workgroup's segment in the stream, dwords it touches
   unsigned long long o0 = 0, o1 = 0;
   if (MODE == WRITE) {
-    // exclusive prefix of this workgroup's block lengths
-    const uint32_t mylen = live ? lens[s] : 0u;
-    uint32_t incl = mylen;
+    // exclusive prefix of this workgroup's block lengths, in scan order: thread i scans position i of the chunk
+    const long long si = chunk * CH + threadIdx.x;
+    const uint32_t len_i = ((int)threadIdx.x < CH && si < sc.nscan) ? lens[si] : 0u;
+    uint32_t incl = len_i;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t up = __shfl_up(incl, o, 64);
@@ -353,7 +369,9 @@ __global__ __launch_bounds__(256) void jpeg_code_kernel(const uint32_t* __restri
     __syncthreads();
     uint32_t before = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before += wsum[k];
-    const unsigned long long bitpos = o0 + before + incl - mylen;
+    pex[threadIdx.x] = before + incl - len_i;   // exclusive prefix of scan position threadIdx.x
+    __syncthreads();
+    const unsigned long long bitpos = o0 + (live ? pex[ls] : 0u);
     bw.start(bw.to_lds ? bitpos - ((unsigned long long)w0 << 5) : bitpos);
   }
 
@@ -644,6 +662,7 @@ bool make_geo(int w, int h, int input_format, int subsampling, Geo& g) {
     g.nbx[c] = g.nmcux * hs;
     const int wc = c == 0 ? w : (w * hs + g.hs0 - 1) / g.hs0;
     g.nbx_real[c] = tdk_div_up(wc, 8);
+    off = (off + 63) & ~63ll;   // a plane starts on a group of the transposed store: 64 consecutive blocks of a wave are one 256-byte row
     g.coff[c] = off;
     off += (long long)g.nbx[c] * g.nmcuy;
   }
@@ -665,7 +684,7 @@ Layout make_layout(const Geo& g) {
   Layout L;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o = tdk_align_up(o + bytes, 256); return at; };
-  L.nwg = (size_t)tdk_div_up64(g.nblocks, 256) + 1;
+  L.nwg = (size_t)tdk_div_up64(g.nblocks, 192) + 1;   // chunks of the coding passes hold 192 or 256 scan positions
   L.raw_cap = tdk_align_up((size_t)g.nblocks * MAX_BLOCK_BYTES + 64, 4096);
   L.nchunk_cap = L.raw_cap / 4096 + 1;
   L.stream_cap = HEADER_CAP + L.raw_cap;
@@ -784,7 +803,8 @@ TDK_EXPORT int tdk_jpeg_encode(const void* image, int width, int height, int inp
     sc.ns = p.ns; sc.comp0 = p.comp0; sc.ss = p.ss; sc.se = p.se;
     if (p.ns > 1) sc.nscan = (long long)g.nmcux * g.nmcuy * (g.hs0 + 2);
     else sc.nscan = (long long)g.nbx_real[p.comp0] * g.nby_real;
-    const unsigned nwg = (unsigned)tdk_div_up64(sc.nscan, 256);
+    sc.chunk = p.ns > 1 ? 64 * (g.hs0 + 2) : 256;
+    const unsigned nwg = (unsigned)tdk_div_up64(sc.nscan, sc.chunk);
 
     TDK_HIP_CALL(hipMemsetAsync(hist, 0, 4096, st), "tdk_jpeg_encode: memset");
     const unsigned nhist = nwg < (unsigned)(persistent / 2) ? nwg : (unsigned)(persistent / 2);
@@ -866,11 +886,13 @@ TDK_EXPORT int tdk_jpeg_coefficients(const void* workspace, int width, int heigh
   std::vector<uint32_t> tmp(nwords);
   TDK_HIP_CALL(hipMemcpyAsync(tmp.data(), reinterpret_cast<const uint8_t*>(workspace) + L.coef, nwords * 4, hipMemcpyDeviceToHost, st), "tdk_jpeg_coefficients: copy");
   TDK_HIP_CALL(hipStreamSynchronize(st), "tdk_jpeg_coefficients: synchronize");
-  for (long long idx = 0; idx < g.nblocks; idx++)
-    for (int j = 0; j < 32; j++) {
-      const uint32_t v = tmp[coef_word(idx, j)];
-      out_host[idx * 64 + 2 * j] = (int16_t)(v & 0xffffu);
-      out_host[idx * 64 + 2 * j + 1] = (int16_t)(v >> 16);
-    }
+  long long o = 0;
+  for (int c = 0; c < g.ncomp; c++)
+    for (long long b = 0; b < (long long)g.nbx[c] * g.nmcuy; b++, o++)
+      for (int j = 0; j < 32; j++) {
+        const uint32_t v = tmp[coef_word(g.coff[c] + b, j)];
+        out_host[o * 64 + 2 * j] = (int16_t)(v & 0xffffu);
+        out_host[o * 64 + 2 * j + 1] = (int16_t)(v >> 16);
+      }
   return TDK_OK;
 }
