@@ -134,3 +134,35 @@ def test_side_stream_and_50mp(td, oracle, dev):
     want = oracle.jpeg_encode(u8.cpu().numpy(), 90, 3, 1, False)
     assert data.shape == want.shape and np.array_equal(data, want)
     assert decode(data).size == (w, h)
+
+
+def test_concurrent_coders_on_their_own_streams(td, oracle, dev):
+    """Three host threads, each with its own coder object and HIP stream (how profiles/raw_to_jpeg.py drives a GPU): the library keeps
+    no process-global state, every call synchronises only its own stream, and each stream still equals the oracle's bytes."""
+    import threading
+
+    imgs = [sample_image(200 + 8 * k, 300 + 16 * k, 40 + k) for k in range(3)]
+    want = [oracle.jpeg_encode(im, 90, 3, k % 3, k == 1) for k, im in enumerate(imgs)]
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            coder = td.Jpeg()
+            x = torch.from_numpy(imgs[k]).to(dev)
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(stream):
+                for _ in range(8):
+                    got = coder.encode(x, 90, td.InputFormat.RGBI, k % 3, k == 1).numpy()
+                    if not np.array_equal(got, want[k]):
+                        errors.append((k, got.shape, want[k].shape))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
